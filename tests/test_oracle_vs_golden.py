@@ -1,0 +1,146 @@
+"""Pins oracle/ref_cpu.py to the reference: every golden vector in tests/golden/*.npz was produced by
+importing the reference's own modules (tests/golden/gen_golden.py).  CPU only."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle import ref_cpu as R
+
+torch.set_num_threads(4)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a)).float()
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert (nan_a == nan_b).all(), f"{what}: NaN pattern differs"
+    np.testing.assert_allclose(a[~nan_a], b[~nan_b], rtol=rtol, atol=atol, err_msg=what)
+
+
+G1, G1META = load_golden("g1_quantizer.npz")
+
+
+@pytest.mark.parametrize("i", range(len(G1META["cases"])))
+def test_quantizer_forward_backward(i):
+    c = G1META["cases"][i]
+    x = T(G1[f"c{i}_x"]).requires_grad_(f"c{i}_gx" in G1)
+    up = T(G1[f"c{i}_up"]).requires_grad_(True) if c["lwc"] else None
+    low = T(G1[f"c{i}_low"]).requires_grad_(True) if c["lwc"] else None
+    y, s, z = R.fake_quant(x, c["n_bits"], c["group_size"], up, low, c["symmetric"], return_qparams=True)
+    close(y.detach(), G1[f"c{i}_y"], what=c["tag"] + " y", rtol=0, atol=0)      # bit-exact
+    close(s.detach(), G1[f"c{i}_scale"], what=c["tag"] + " scale", rtol=0, atol=0)
+    close(z.detach(), G1[f"c{i}_zp"], what=c["tag"] + " zp", rtol=0, atol=0)
+    if y.requires_grad:
+        (y * T(G1[f"c{i}_G"])).sum().backward()
+        if x.grad is not None:
+            close(x.grad, G1[f"c{i}_gx"], what=c["tag"] + " gx", rtol=1e-6, atol=1e-7)
+        if c["lwc"]:
+            close(up.grad, G1[f"c{i}_gup"], what=c["tag"] + " gup", rtol=1e-5, atol=1e-6)
+            close(low.grad, G1[f"c{i}_glow"], what=c["tag"] + " glow", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("i", [i for i, c in enumerate(G1META["cases"])
+                               if not c["symmetric"] and f"c{i}_gx" in G1 and c["n_bits"] < 16])
+def test_quantizer_closed_form_backward(i):
+    c = G1META["cases"][i]
+    x = T(G1[f"c{i}_x"])
+    up = T(G1[f"c{i}_up"]) if c["lwc"] else None
+    low = T(G1[f"c{i}_low"]) if c["lwc"] else None
+    gx, gup, glow = R.fake_quant_backward(x, T(G1[f"c{i}_G"]), c["n_bits"], c["group_size"], up, low)
+    # gs = sum G*((q-z) - x/s) cancels catastrophically when |x/s| is large (x ~ 100, s ~ 1/15):
+    # fp32 noise there is ~1e-7 * |x/s| per element, in the reference's autograd as well.
+    atol = 5e-4 if c["tag"] == "a4_tok_positive" else 2e-5
+    close(gx, G1[f"c{i}_gx"], what=c["tag"] + " gx", rtol=1e-5, atol=atol)
+    if c["lwc"]:
+        close(gup, G1[f"c{i}_gup"], what=c["tag"] + " gup", rtol=1e-4, atol=2e-5)
+        close(glow, G1[f"c{i}_glow"], what=c["tag"] + " glow", rtol=1e-4, atol=2e-5)
+
+
+def test_truncate_and_let_init():
+    g, _ = load_golden("g5_misc.npz")
+    close(R.truncate_small(T(g["trunc_x"])), g["trunc_y"], rtol=0, atol=0)
+    for alpha in (0.5, 0.75):
+        close(R.let_init_scale(T(g["let_act"]), T(g["let_W"]), alpha), g[f"let_scale_a{alpha}"], rtol=1e-6)
+
+
+def _spec(meta):
+    return R.QuantSpec(meta["wbits"], meta["abits"], meta["group_size"], meta["lwc"], meta["let"])
+
+
+def _block_from_step(g, meta):
+    weights = {k[2:]: T(v) for k, v in g.items() if k.startswith("w.")}
+    blk = R.Block(meta["family"], meta["config"], weights, _spec(meta))
+    if meta["let"]:
+        sc = {k[len("act_scales."):]: T(v) for k, v in g.items() if k.startswith("act_scales.")}
+        sh = {k[len("act_shifts."):]: T(v) for k, v in g.items() if k.startswith("act_shifts.")}
+        blk.register_let(sc, sh, meta["alpha"], 0, meta["layer_prefix"])
+    for n in list(blk.params.keys()):
+        blk.params[n] = T(g["p0." + n]).requires_grad_(True)
+    return blk
+
+
+STEP_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g3_step_*.npz")))
+
+
+@pytest.mark.parametrize("fname", STEP_FILES)
+def test_block_step(fname):
+    g, meta = load_golden(fname)
+    blk = _block_from_step(g, meta)
+    assert {("p0." + n) for n in blk.params} == {k for k in g if k.startswith("p0.")}
+    x, tgt, mask = T(g["x"]), T(g["target"]), T(g["mask"])
+    pos = torch.from_numpy(g["position_ids"])
+    temps = blk.temporaries()
+    for k, v in g.items():
+        if k.startswith("tmp."):
+            mod, kind = k[4:].rsplit(".temp_", 1)
+            close(temps[f"{mod}.{kind}"].detach(), v, rtol=1e-6, atol=1e-7, what=k)
+        if k.startswith("p_trunc."):
+            close(blk.params[k[8:]].detach(), v, rtol=0, atol=0, what=k)
+    out = blk.forward(x, mask, pos, temps=temps, act_quant=True)
+    close(out.detach(), g["out"], rtol=2e-4, atol=2e-5, what="out")
+    loss = torch.nn.functional.mse_loss(tgt, out)
+    close(loss.detach().reshape(1), g["loss"].reshape(1), rtol=1e-5, what="loss")
+    loss.backward()
+    for n, p in blk.params.items():
+        ref = g["grad." + n]
+        scale = max(np.abs(ref).max(), 1e-12)
+        close(p.grad / scale, ref / scale, rtol=2e-3, atol=2e-5, what="grad " + n)
+    with torch.no_grad():
+        close(blk.forward(x, mask, pos, temps=None, act_quant=False), g["out_fp"], rtol=1e-5, atol=1e-5, what="fp")
+
+
+TRAJ_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g4_traj_*.npz")))
+
+
+@pytest.mark.parametrize("fname", TRAJ_FILES)
+def test_trajectory(fname):
+    g, m = load_golden(fname)
+    layers = [{k[len(f"w{i}."):]: T(v) for k, v in g.items() if k.startswith(f"w{i}.")} for i in range(m["n_layers"])]
+    sc = {k[len("act_scales."):]: T(v) for k, v in g.items() if k.startswith("act_scales.")}
+    sh = {k[len("act_shifts."):]: T(v) for k, v in g.items() if k.startswith("act_shifts.")}
+    res = R.calibrate(m["family"], m["config"], layers, _spec(m), T(g["inps"]), T(g["mask"]),
+                      torch.from_numpy(g["position_ids"]), sc, sh, epochs=m["epochs"], let_lr=m["let_lr"],
+                      lwc_lr=m["lwc_lr"], alpha=m["alpha"], aug_loss=m["aug_loss"], prefix=m["layer_prefix"])
+    close(res["losses"], g["losses"], rtol=2e-3, what="losses")
+    close(res["norms"], g["norms"], rtol=2e-2, what="norms")
+    for i in range(m["n_layers"]):
+        close(res["fp_out"][i], g[f"fp_out.{i}"], rtol=1e-4, atol=1e-4, what=f"fp_out {i}")
+        keys = [k for k in g if k.startswith(f"omni.{i}.")]
+        assert {k[len(f"omni.{i}."):] for k in keys} == set(res["omni"][i].keys())
+        for k in keys:
+            n = k[len(f"omni.{i}."):]
+            ref = g[k].astype(np.float64)
+            got = res["omni"][i][n].float().numpy()
+            assert res["omni"][i][n].dtype == torch.float16
+            # north-star bar: learned tensors within 1e-3 relative (to the tensor's scale)
+            tol = 1e-3 * max(np.abs(ref).max(), 1e-6)
+            assert np.abs(got - ref).max() <= tol + 1e-3 * 0, f"{n}: {np.abs(got-ref).max()} > {tol}"
+        close(res["quant_out"][i], g[f"quant_out.{i}"], rtol=5e-2, atol=5e-2, what=f"quant_out {i}")
