@@ -1,0 +1,141 @@
+/*
+ * oq_hip.h -- C ABI of the MI355X (gfx950) OmniQuant calibration hot path.
+ *
+ * The reference (SuperVan-Young/OmniQuant) has no FFI: its hot path is PyTorch eager ops inside three
+ * nn.Modules.  This header is the boundary a maintainer binds instead of those op sequences; every
+ * entry point cites the reference lines it replaces.  All pointers are DEVICE pointers owned by the
+ * caller (PyTorch-ROCm allocations), all calls are asynchronous on `stream` (a hipStream_t passed as
+ * void*), never allocate, never synchronise, and are hipGraph-capturable.  Return 0 on success or a
+ * negative OQ_E_* code; the message for the last error of the calling thread is oq_last_error().
+ *
+ * dtype codes: OQ_F32 = 0, OQ_F16 = 1, OQ_BF16 = 2.
+ * "seg" is the quantisation segment along the last dim: a whole row (per-channel / per-token),
+ * a weight group (group_size) or a head (head_dim).
+ */
+#ifndef OQ_HIP_H
+#define OQ_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OQ_F32 0
+#define OQ_F16 1
+#define OQ_BF16 2
+
+#define OQ_OK 0
+#define OQ_E_ARG (-1)      /* bad argument (shape, alignment, dtype) */
+#define OQ_E_LAUNCH (-2)   /* HIP launch failure */
+#define OQ_E_UNSUPPORTED (-3)
+
+int oq_version(void);
+const char* oq_last_error(void);
+
+/* ---- UniformAffineQuantizer: dynamic min/max + LWC + fake quant ---------------------------------
+ * Replaces quantize/quantizer.py:84-105 (fake_quant), :122-147 (per_token_dynamic_calibration),
+ * :15-19 (round_ste) and, for weights, the LET re-parameterisation that feeds it:
+ * models/transformation.py:24-69 (W*col_mul, /row_div, *row_mul and the W@shift bias term).
+ *
+ *   x[r,c]   = ((w[r,c] * col_mul[c]) / row_div[r]) * row_mul[r]          (each factor optional)
+ *   per segment:  hi = max x, lo = min x;  hi' = sigmoid(up)*hi, lo' = sigmoid(low)*lo  (LWC, optional)
+ *   asymmetric:   s = (hi'-lo')/(2^n-1),  z = rne(clamp(-lo'/s, +-1e4))
+ *   symmetric:    s = clamp(max(|hi'|,|lo'|)/(2^(n-1)-1), 1e-5, 1e4),  z = 2^(n-1)-1
+ *   y = (clamp(rne(x/s)+z, 0, 2^n-1) - z) * s
+ *   wshift[r] = sum_c w[r,c]*shift[c]                                      (optional by-product)
+ * Outputs: y [rows,cols] (y_dtype); scale, zp, xmin, xmax [rows*cols/seg] f32 (each may be NULL).
+ * Requirements: cols % seg == 0, seg % 8 == 0, and seg/8 a power of two when seg <= 512.
+ */
+int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits, int symmetric,
+                     const float* col_mul, const float* row_div, const float* row_mul, const float* shift,
+                     const float* up, const float* low,
+                     void* y, int y_dtype, float* scale, float* zp, float* xmin, float* xmax, float* wshift,
+                     void* stream);
+
+/* Backward of the above (closed form of the autograd graph the reference builds).
+ *   g [rows,cols] (g_dtype) = dL/dy ; g_wshift [rows] = dL/d wshift (optional)
+ * Outputs (each optional, f32): g_up, g_low [rows*cols/seg]; gx [rows,cols] (gx_dtype; only when w itself
+ * needs a gradient, i.e. activation quantizers); g_col_mul [cols], g_shift [cols] (ACCUMULATED with float
+ * atomics: caller zeroes them); g_row_div, g_row_mul [rows].
+ */
+int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits, int symmetric,
+                     const float* col_mul, const float* row_div, const float* row_mul, const float* shift,
+                     const float* up, const float* low,
+                     const void* g, int g_dtype, const float* g_wshift,
+                     float* g_up, float* g_low, void* gx, int gx_dtype,
+                     float* g_col_mul, float* g_shift, float* g_row_div, float* g_row_mul,
+                     void* stream);
+
+/* ---- QuantLinear / QuantMatMul GEMM (quantize/int_linear.py:62 F.linear; quantize/int_matmul.py:41-43
+ * torch.matmul / torch.bmm, and their autograd: dgrad + wgrad) -------------------------------------------
+ *   C[b][m][n] = alpha * sum_k A(b,m,k) * B(b,n,k) + bias[n]
+ *   A(b,m,k) = a[bo*sa_o + bi*sa_i + (a_kc ? m*lda + k : k*lda + m)]   (b = bo*batch_i + bi)
+ *   B(b,n,k) = bm[bo*sb_o + bi*sb_i + (b_kc ? n*ldb + k : k*ldb + n)]
+ *   C        = c[bo*sc_o + bi*sc_i + m*ldc + n]
+ * in_dtype OQ_BF16: bf16 operands on v_mfma_f32_16x16x32_bf16, f32 accumulate.
+ * in_dtype OQ_F32 : exact f32 on v_mfma_f32_16x16x4_f32 (parity mode).
+ * out_dtype OQ_F32 or OQ_BF16.  Alignment: contiguous dims and leading dims multiples of 8 elements.
+ */
+int oq_gemm(const void* a, const void* bm, void* c, const float* bias,
+            int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+            int a_kc, int b_kc, int in_dtype, int out_dtype, float alpha,
+            int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
+            int64_t sc_o, int64_t sc_i, void* stream);
+
+/* column sums: out[n] = sum_m x[m,n]  (bias gradients).  out f32, zeroed by the callee. */
+int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, float* out, void* stream);
+
+/* ---- OmniLlamaRMSNorm / OmniLayerNorm (quantize/omni_norm.py:26-34, :52-63) -----------------------------
+ * rms:  y = w * x * rsqrt(mean(x^2)+eps) (+ b);   layer: y = w * (x-mean)/sqrt(var+eps) + b.   w,b f32.
+ * bwd: gx [rows,cols]; gw, gb [cols] f32 ACCUMULATED with atomics (caller zeroes). b / gb may be NULL.
+ */
+int oq_norm_fwd(const void* x, int dtype, int64_t rows, int64_t cols, const float* w, const float* b, float eps,
+                int is_layernorm, void* y, float* rstd, float* mean, void* stream);
+int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t rows, int64_t cols, const float* w,
+                const float* rstd, const float* mean, int is_layernorm, void* gx, float* gw, float* gb, void* stream);
+
+/* ---- block glue (models/int_llama_layer.py:124-125 RoPE, :44-45 SiLU*up, :153-163 mask+softmax;
+ *      models/int_opt_layer.py:151-170; quantize/omniquant.py:220-222 MSE) ---------------------------------
+ * rope: x [T, heads, hd] in place-capable; cos/sin f32 [T, hd] already gathered by position_ids.
+ *       inverse!=0 applies the transposed rotation (backward).
+ * softmax: p = softmax(max(s*alpha + mask[row % mask_rows], lowest)) over the last dim, f32 math.
+ *       rows = batch*heads*Tq; mask f32 [mask_rows, cols] or NULL.
+ */
+int oq_rope(const void* x, void* y, int dtype, int64_t T, int64_t heads, int64_t hd, const float* cos, const float* sin,
+            int inverse, void* stream);
+int oq_silu_mul_fwd(const void* gate, const void* up, void* y, int dtype, int64_t n, void* stream);
+int oq_silu_mul_bwd(const void* gate, const void* up, const void* gy, void* ggate, void* gup, int dtype, int64_t n,
+                    void* stream);
+int oq_relu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream);
+int oq_relu_bwd(const void* x, const void* gy, void* gx, int dtype, int64_t n, void* stream);
+int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols, float alpha, const float* mask,
+                   int64_t mask_rows, void* stream);
+int oq_softmax_bwd(const void* p, const void* gp, void* gs, int dtype, int64_t rows, int64_t cols, float alpha,
+                   void* stream);
+/* loss[0] += mean((out-t1)^2) (+ mean((out-t2)^2) if t2); g = dloss/dout * gscale.  loss zeroed by caller. */
+int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, int dtype, int64_t n, float gscale,
+                   float* loss, void* g, void* stream);
+/* y = a + b (residual) and y = a * s (OPT query scaling) */
+int oq_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
+int oq_scale(const void* a, float s, void* y, int dtype, int64_t n, void* stream);
+
+/* ---- optimiser (utils.py:11-24,32-46; torch.optim.AdamW at quantize/omniquant.py:207-208;
+ *      models/transformation.py:5-20 truncate_number) ----------------------------------------------------
+ * Learnables of a block live in ONE flat f32 arena: [0,n_let) LET params (lr_let), [n_let,n) LWC (lr_lwc).
+ * oq_gradnorm: norm_out[0] = ||g||_2 (f32), norm_out[1] = 1.0 if every element is finite else 0.0.
+ * oq_adamw: torch.optim.AdamW update with bias correction for `step` (read from step_ptr[0], f32 counter
+ *   kept on device so the call is graph-replayable; incremented by the kernel when the step is applied).
+ *   The update is skipped (GradScaler semantics, utils.py:42-43) when norm[1]==0.
+ * oq_truncate: |x|<thr -> sign(x)*thr in place.
+ */
+int oq_gradnorm(const float* g, int64_t n, float* norm_out, float* workspace, void* stream);
+int oq_adamw(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_let, float lr_let, float lr_lwc,
+             float beta1, float beta2, float eps, float wd, float* step_ptr, const float* norm, void* stream);
+int oq_truncate(float* x, int64_t n, float thr, void* stream);
+
+/* dtype conversion with round-to-nearest-even */
+int oq_cast(const void* x, int src_dtype, void* y, int dst_dtype, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""ctypes binding of the gfx950 C-ABI library (include/oq_hip.h -> omniquant_amd/lib/liboq_hip.so).
+
+There is NO fallback: if the library is missing or a call fails, an exception is raised.  PyTorch is used
+only as the owner of device memory and of the HIP stream the kernels are enqueued on.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liboq_hip.so")
+
+OQ_F32, OQ_F16, OQ_BF16 = 0, 1, 2
+_DT = {torch.float32: OQ_F32, torch.float16: OQ_F16, torch.bfloat16: OQ_BF16}
+
+_i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes, exactly as declared in include/oq_hip.h (tests/test_capi_symbols.py cross-checks the header)
+SIGNATURES = {
+    "oq_fakequant_fwd": [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                         _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "oq_fakequant_bwd": [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                         _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    "oq_gemm": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
+                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp],
+    "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp],
+    "oq_norm_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
+    "oq_norm_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "oq_rope": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
+    "oq_silu_mul_fwd": [_vp, _vp, _vp, _i32, _i64, _vp],
+    "oq_silu_mul_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
+    "oq_relu_fwd": [_vp, _vp, _i32, _i64, _vp],
+    "oq_relu_bwd": [_vp, _vp, _vp, _i32, _i64, _vp],
+    "oq_softmax_fwd": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _i64, _vp],
+    "oq_softmax_bwd": [_vp, _vp, _vp, _i32, _i64, _i64, _f32, _vp],
+    "oq_mse_fwd_bwd": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],
+    "oq_add": [_vp, _vp, _vp, _i32, _i64, _vp],
+    "oq_scale": [_vp, _f32, _vp, _i32, _i64, _vp],
+    "oq_gradnorm": [_vp, _i64, _vp, _vp, _vp],
+    "oq_adamw": [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp],
+    "oq_truncate": [_vp, _i64, _f32, _vp],
+    "oq_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
+}
+
+_lib = None
+
+
+class OQError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liboq_hip.so (built by __graft_entry__.build() / `make -C omniquant_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OQError(f"{LIB_PATH} is missing: the HIP extension is not built "
+                      "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.oq_version.restype = ctypes.c_int
+    lib.oq_last_error.restype = ctypes.c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise OQError(f"{name} failed (rc={rc}): {lib.oq_last_error().decode()}")
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise OQError(f"dtype {t.dtype} is not supported by the HIP path")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Tensors must live on the GPU and be contiguous."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise OQError("the OmniQuant HIP path needs GPU tensors (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise OQError("non-contiguous tensor passed to the HIP path")
+    return t.data_ptr()
+
+
+def fptr(t):
+    """float32 device pointer."""
+    if t is not None and t.dtype != torch.float32:
+        raise OQError(f"expected a float32 tensor, got {t.dtype}")
+    return ptr(t)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,118 @@
+// Shared device/host helpers for the gfx950 kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/oq_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+void oq_set_error(const char* fmt, ...);
+
+#define OQ_CHECK_ARG(cond, ...)            \
+    do {                                   \
+        if (!(cond)) {                     \
+            oq_set_error(__VA_ARGS__);     \
+            return OQ_E_ARG;               \
+        }                                  \
+    } while (0)
+
+#define OQ_CHECK_LAUNCH(name)                                                      \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            oq_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));   \
+            return OQ_E_LAUNCH;                                                    \
+        }                                                                          \
+    } while (0)
+
+// ---- element load/store: 8 consecutive elements per lane as f32 ---------------------------------
+template <typename T>
+struct Vec8;
+
+template <>
+struct Vec8<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+        f32x4 a = *reinterpret_cast<const f32x4*>(p);
+        f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[8]) {
+        f32x4 a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = v[i]; b[i] = v[4 + i]; }
+        *reinterpret_cast<f32x4*>(p) = a;
+        *reinterpret_cast<f32x4*>(p + 4) = b;
+    }
+};
+
+template <>
+struct Vec8<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __builtin_bit_cast(float, r[i] << 16);
+            v[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        bf16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (bf16_t)v[i];   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+        *reinterpret_cast<bf16x8*>(p) = o;
+    }
+};
+
+template <>
+struct Vec8<f16_t> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    static __device__ __forceinline__ void load(const f16_t* p, float (&v)[8]) {
+        h8 r = *reinterpret_cast<const h8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)r[i];
+    }
+    static __device__ __forceinline__ void store(f16_t* p, const float (&v)[8]) {
+        h8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (f16_t)v[i];
+        *reinterpret_cast<h8*>(p) = o;
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
+template <typename T>
+__device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
+
+// ---- wave-level reductions (width = power of two <= 64, lanes grouped contiguously) -------------
+__device__ __forceinline__ float wave_sum(float v, int width = 64) {
+    for (int m = width >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v, int width = 64) {
+    for (int m = width >> 1; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v, int width = 64) {
+    for (int m = width >> 1; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+// NaN-propagating variants: torch.amax/amin propagate NaN, fmaxf does not.
+__device__ __forceinline__ float nmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
+__device__ __forceinline__ float nmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+static inline int oq_dtype_size(int dt) { return dt == OQ_F32 ? 4 : 2; }
+static inline bool oq_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -1,0 +1,367 @@
+// Block glue kernels for gfx950: RoPE, SiLU*up, ReLU, masked softmax (fwd/bwd), fused MSE loss + gradient,
+// residual add, scaling, dtype cast, column sums.  All HBM-bound streaming kernels: 16-byte vector accesses,
+// grid-stride, f32 math.
+// Reference lines: models/int_llama_layer.py:44-45,124-125,153-163; models/int_opt_layer.py:96,151-170,307;
+// quantize/omniquant.py:220-222.
+#include "oq_common.h"
+
+namespace {
+
+inline int64_t ew_grid(int64_t nvec, int bt = 256) {
+    int64_t g = (nvec + bt - 1) / bt;
+    return g < 1 ? 1 : (g > 4096 ? 4096 : g);
+}
+
+// ---- RoPE: x [T, heads, hd]; cos/sin [T, hd] ---------------------------------------------------------
+// y = x*cos + rot_half(x)*sin ; rot_half(x) = cat(-x[hd/2:], x[:hd/2]).
+// inverse (gradient): gx = g*cos + rot_half^T(g*sin), rot_half^T(u) = cat(u[hd/2:], -u[:hd/2]).
+template <typename T>
+__global__ void rope_kernel(const T* x, T* y, int64_t Tn, int64_t heads, int64_t hd, const float* cs, const float* sn,
+                            int inverse) {
+    const int64_t half = hd / 2;
+    const int64_t nvec = Tn * heads * (half / 8);   // each item handles 8 elements of the first half + partner 8
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t d0 = (v % (half / 8)) * 8;
+        const int64_t th = v / (half / 8);
+        const int64_t tt = th / heads;
+        const T* px = x + th * hd;
+        T* py = y + th * hd;
+        float a[8], b[8], oa[8], ob[8];
+        Vec8<T>::load(px + d0, a);
+        Vec8<T>::load(px + half + d0, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float c1 = cs[tt * hd + d0 + i], s1 = sn[tt * hd + d0 + i];
+            const float c2 = cs[tt * hd + half + d0 + i], s2 = sn[tt * hd + half + d0 + i];
+            if (!inverse) {
+                oa[i] = a[i] * c1 + (-b[i]) * s1;
+                ob[i] = b[i] * c2 + a[i] * s2;
+            } else {
+                oa[i] = a[i] * c1 + b[i] * s2;
+                ob[i] = b[i] * c2 - a[i] * s1;
+            }
+        }
+        Vec8<T>::store(py + d0, oa);
+        Vec8<T>::store(py + half + d0, ob);
+    }
+}
+
+template <typename T, int OP>   // 0 silu*up fwd, 1 relu fwd, 2 add, 3 scale
+__global__ void ew_fwd_kernel(const T* a, const T* b, T* y, int64_t n, float s) {
+    const int64_t nvec = n / 8;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], u[8], o[8];
+        Vec8<T>::load(a + v * 8, x);
+        if (OP == 0 || OP == 2) Vec8<T>::load(b + v * 8, u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (OP == 0) o[i] = (x[i] / (1.f + expf(-x[i]))) * u[i];
+            if (OP == 1) o[i] = x[i] > 0.f ? x[i] : 0.f;
+            if (OP == 2) o[i] = x[i] + u[i];
+            if (OP == 3) o[i] = x[i] * s;
+        }
+        Vec8<T>::store(y + v * 8, o);
+    }
+}
+
+template <typename T>
+__global__ void silu_mul_bwd_kernel(const T* gate, const T* up, const T* gy, T* gg, T* gu, int64_t n) {
+    const int64_t nvec = n / 8;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        float x[8], u[8], g[8], og[8], ou[8];
+        Vec8<T>::load(gate + v * 8, x);
+        Vec8<T>::load(up + v * 8, u);
+        Vec8<T>::load(gy + v * 8, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float sg = 1.f / (1.f + expf(-x[i]));
+            const float silu = x[i] * sg;
+            ou[i] = g[i] * silu;
+            og[i] = g[i] * u[i] * (sg * (1.f + x[i] * (1.f - sg)));
+        }
+        Vec8<T>::store(gg + v * 8, og);
+        Vec8<T>::store(gu + v * 8, ou);
+    }
+}
+
+template <typename T>
+__global__ void relu_bwd_kernel(const T* x, const T* gy, T* gx, int64_t n) {
+    const int64_t nvec = n / 8;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        float a[8], g[8], o[8];
+        Vec8<T>::load(x + v * 8, a);
+        Vec8<T>::load(gy + v * 8, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = a[i] > 0.f ? g[i] : 0.f;
+        Vec8<T>::store(gx + v * 8, o);
+    }
+}
+
+// ---- masked softmax: one wave per row, row in registers when cols <= 64*8*SM_CH ------------------------
+constexpr int SM_CH = 8;   // 8 chunks * 8 elems * 64 lanes = 4096 columns max per wave-row
+
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(const T* s, T* p, int64_t rows, int64_t cols, float alpha,
+                                                          const float* mask, int64_t mask_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const float lowest = -3.4028234663852886e38f;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        float v[SM_CH][8];
+        float mx = -INFINITY;
+        const float* mrow = mask ? mask + (r % mask_rows) * cols : nullptr;
+#pragma unroll
+        for (int j = 0; j < SM_CH; ++j) {
+            const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
+            if (c0 < cols) {
+                Vec8<T>::load(s + r * cols + c0, v[j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float z = v[j][i] * alpha;
+                    if (mrow) z = fmaxf(z + mrow[c0 + i], lowest);
+                    v[j][i] = z;
+                    mx = fmaxf(mx, z);
+                }
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < SM_CH; ++j) {
+            const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
+            if (c0 < cols) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { v[j][i] = expf(v[j][i] - mx); sum += v[j][i]; }
+            }
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int j = 0; j < SM_CH; ++j) {
+            const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
+            if (c0 < cols) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = v[j][i] * inv;
+                Vec8<T>::store(p + r * cols + c0, o);
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const T* p, const T* gp, T* gs, int64_t rows, int64_t cols,
+                                                          float alpha) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < rows; r += nwaves) {
+        float pv[SM_CH][8], gv[SM_CH][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < SM_CH; ++j) {
+            const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
+            if (c0 < cols) {
+                Vec8<T>::load(p + r * cols + c0, pv[j]);
+                Vec8<T>::load(gp + r * cols + c0, gv[j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) dot += pv[j][i] * gv[j][i];
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int j = 0; j < SM_CH; ++j) {
+            const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
+            if (c0 < cols) {
+                float o[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = pv[j][i] * (gv[j][i] - dot) * alpha;
+                Vec8<T>::store(gs + r * cols + c0, o);
+            }
+        }
+    }
+}
+
+// ---- MSE loss + gradient -------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) mse_kernel(const T* out, const T* t1, const T* t2, int64_t n, float gscale,
+                                                  float* loss, T* g) {
+    __shared__ float red[4];
+    const int64_t nvec = n / 8;
+    const float inv_n = 1.f / (float)n;
+    float acc = 0.f;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        float o[8], a[8], b[8], gg[8];
+        Vec8<T>::load(out + v * 8, o);
+        Vec8<T>::load(t1 + v * 8, a);
+        if (t2) Vec8<T>::load(t2 + v * 8, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float d = o[i] - a[i];
+            acc += d * d;
+            float gr = 2.f * d;
+            if (t2) { const float d2 = o[i] - b[i]; acc += d2 * d2; gr += 2.f * d2; }
+            gg[i] = gr * inv_n * gscale;
+        }
+        Vec8<T>::store(g + v * 8, gg);
+    }
+    acc = wave_sum(acc);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) red[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* x, TD* y, int64_t n) {
+    const int64_t nvec = n / 8;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        float a[8];
+        Vec8<TS>::load(x + v * 8, a);
+        Vec8<TD>::store(y + v * 8, a);
+    }
+}
+
+// column sums: block handles 64 columns x a slab of rows; lanes along columns (coalesced), then atomics
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* x, int64_t rows, int64_t cols, float* out) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const int64_t rows_per = (rows + gridDim.y - 1) / gridDim.y;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+    const int64_t r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
+    float acc = 0.f;
+    if (c < cols)
+        for (int64_t r = r0 + wid; r < r1; r += 4) acc += ld1(x + r * cols + c);
+    red[wid][lane] = acc;
+    __syncthreads();
+    if (wid == 0 && c < cols) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+}  // namespace
+
+#define EW_CHECK(fn, n) OQ_CHECK_ARG((n) > 0 && (n) % 8 == 0, fn ": n=%lld must be a positive multiple of 8", (long long)(n))
+#define DT_SWITCH(fn, dtype, CALL_F32, CALL_BF16)                 \
+    do {                                                          \
+        if ((dtype) == OQ_F32) { CALL_F32; }                      \
+        else if ((dtype) == OQ_BF16) { CALL_BF16; }               \
+        else { oq_set_error(fn ": dtype %d unsupported", dtype); return OQ_E_UNSUPPORTED; } \
+        OQ_CHECK_LAUNCH(fn);                                      \
+        return OQ_OK;                                             \
+    } while (0)
+
+extern "C" int oq_rope(const void* x, void* y, int dtype, int64_t T, int64_t heads, int64_t hd, const float* cos,
+                       const float* sin, int inverse, void* stream) {
+    OQ_CHECK_ARG(x && y && cos && sin, "oq_rope: null pointer");
+    OQ_CHECK_ARG(T > 0 && heads > 0 && hd > 0 && hd % 16 == 0, "oq_rope: head_dim %lld must be a multiple of 16", (long long)hd);
+    const int64_t nvec = T * heads * (hd / 16);
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH("oq_rope", dtype,
+              hipLaunchKernelGGL((rope_kernel<float>), dim3(ew_grid(nvec)), dim3(256), 0, st, (const float*)x, (float*)y, T, heads, hd, cos, sin, inverse),
+              hipLaunchKernelGGL((rope_kernel<bf16_t>), dim3(ew_grid(nvec)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, T, heads, hd, cos, sin, inverse));
+}
+
+#define EW_FWD(NAME, OP, A, B, S)                                                                                          \
+    hipStream_t st = (hipStream_t)stream;                                                                                  \
+    DT_SWITCH(NAME, dtype,                                                                                                 \
+              hipLaunchKernelGGL((ew_fwd_kernel<float, OP>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const float*)A, (const float*)B, (float*)y, n, S), \
+              hipLaunchKernelGGL((ew_fwd_kernel<bf16_t, OP>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B, (bf16_t*)y, n, S))
+
+extern "C" int oq_silu_mul_fwd(const void* gate, const void* up, void* y, int dtype, int64_t n, void* stream) {
+    EW_CHECK("oq_silu_mul_fwd", n);
+    EW_FWD("oq_silu_mul_fwd", 0, gate, up, 0.f);
+}
+extern "C" int oq_relu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream) {
+    EW_CHECK("oq_relu_fwd", n);
+    EW_FWD("oq_relu_fwd", 1, x, x, 0.f);
+}
+extern "C" int oq_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream) {
+    EW_CHECK("oq_add", n);
+    EW_FWD("oq_add", 2, a, b, 0.f);
+}
+extern "C" int oq_scale(const void* a, float s, void* y, int dtype, int64_t n, void* stream) {
+    EW_CHECK("oq_scale", n);
+    EW_FWD("oq_scale", 3, a, a, s);
+}
+
+extern "C" int oq_silu_mul_bwd(const void* gate, const void* up, const void* gy, void* ggate, void* gup, int dtype,
+                               int64_t n, void* stream) {
+    EW_CHECK("oq_silu_mul_bwd", n);
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH("oq_silu_mul_bwd", dtype,
+              hipLaunchKernelGGL((silu_mul_bwd_kernel<float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const float*)gate, (const float*)up, (const float*)gy, (float*)ggate, (float*)gup, n),
+              hipLaunchKernelGGL((silu_mul_bwd_kernel<bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)gate, (const bf16_t*)up, (const bf16_t*)gy, (bf16_t*)ggate, (bf16_t*)gup, n));
+}
+
+extern "C" int oq_relu_bwd(const void* x, const void* gy, void* gx, int dtype, int64_t n, void* stream) {
+    EW_CHECK("oq_relu_bwd", n);
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH("oq_relu_bwd", dtype,
+              hipLaunchKernelGGL((relu_bwd_kernel<float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const float*)x, (const float*)gy, (float*)gx, n),
+              hipLaunchKernelGGL((relu_bwd_kernel<bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)gy, (bf16_t*)gx, n));
+}
+
+extern "C" int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols, float alpha,
+                              const float* mask, int64_t mask_rows, void* stream) {
+    OQ_CHECK_ARG(s && p, "oq_softmax_fwd: null pointer");
+    OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 64 * 8 * SM_CH, "oq_softmax_fwd: cols %lld (multiple of 8, <= %d)", (long long)cols, 64 * 8 * SM_CH);
+    OQ_CHECK_ARG(!mask || mask_rows > 0, "oq_softmax_fwd: mask_rows");
+    const int64_t grid = (rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192;
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH("oq_softmax_fwd", dtype,
+              hipLaunchKernelGGL((softmax_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)s, (float*)p, rows, cols, alpha, mask, mask_rows),
+              hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)s, (bf16_t*)p, rows, cols, alpha, mask, mask_rows));
+}
+
+extern "C" int oq_softmax_bwd(const void* p, const void* gp, void* gs, int dtype, int64_t rows, int64_t cols,
+                              float alpha, void* stream) {
+    OQ_CHECK_ARG(p && gp && gs, "oq_softmax_bwd: null pointer");
+    OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 64 * 8 * SM_CH, "oq_softmax_bwd: cols %lld", (long long)cols);
+    const int64_t grid = (rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192;
+    hipStream_t st = (hipStream_t)stream;
+    DT_SWITCH("oq_softmax_bwd", dtype,
+              hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)p, (const float*)gp, (float*)gs, rows, cols, alpha),
+              hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)p, (const bf16_t*)gp, (bf16_t*)gs, rows, cols, alpha));
+}
+
+extern "C" int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, int dtype, int64_t n, float gscale,
+                              float* loss, void* g, void* stream) {
+    EW_CHECK("oq_mse_fwd_bwd", n);
+    OQ_CHECK_ARG(out && t1 && loss && g, "oq_mse_fwd_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t grid = ew_grid(n / 8) > 1024 ? 1024 : ew_grid(n / 8);
+    DT_SWITCH("oq_mse_fwd_bwd", dtype,
+              hipLaunchKernelGGL((mse_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)out, (const float*)t1, (const float*)t2, n, gscale, loss, (float*)g),
+              hipLaunchKernelGGL((mse_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)t1, (const bf16_t*)t2, n, gscale, loss, (bf16_t*)g));
+}
+
+extern "C" int oq_cast(const void* x, int src_dtype, void* y, int dst_dtype, int64_t n, void* stream) {
+    EW_CHECK("oq_cast", n);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(ew_grid(n / 8)), blk(256);
+    const int key = src_dtype * 3 + dst_dtype;
+    switch (key) {
+        case OQ_F32 * 3 + OQ_BF16: hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, blk, 0, st, (const float*)x, (bf16_t*)y, n); break;
+        case OQ_F32 * 3 + OQ_F16: hipLaunchKernelGGL((cast_kernel<float, f16_t>), grid, blk, 0, st, (const float*)x, (f16_t*)y, n); break;
+        case OQ_BF16 * 3 + OQ_F32: hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, blk, 0, st, (const bf16_t*)x, (float*)y, n); break;
+        case OQ_F16 * 3 + OQ_F32: hipLaunchKernelGGL((cast_kernel<f16_t, float>), grid, blk, 0, st, (const f16_t*)x, (float*)y, n); break;
+        case OQ_F16 * 3 + OQ_BF16: hipLaunchKernelGGL((cast_kernel<f16_t, bf16_t>), grid, blk, 0, st, (const f16_t*)x, (bf16_t*)y, n); break;
+        case OQ_BF16 * 3 + OQ_F16: hipLaunchKernelGGL((cast_kernel<bf16_t, f16_t>), grid, blk, 0, st, (const bf16_t*)x, (f16_t*)y, n); break;
+        default: oq_set_error("oq_cast: %d -> %d unsupported", src_dtype, dst_dtype); return OQ_E_UNSUPPORTED;
+    }
+    OQ_CHECK_LAUNCH("oq_cast");
+    return OQ_OK;
+}
+
+extern "C" int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, float* out, void* stream) {
+    OQ_CHECK_ARG(x && out && rows > 0 && cols > 0, "oq_colsum: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, cols * sizeof(float), st) != hipSuccess) { oq_set_error("oq_colsum: memset failed"); return OQ_E_LAUNCH; }
+    int64_t gy = rows / 64; gy = gy < 1 ? 1 : (gy > 64 ? 64 : gy);
+    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)gy);
+    DT_SWITCH("oq_colsum", dtype,
+              hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, cols, out),
+              hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, rows, cols, out));
+}

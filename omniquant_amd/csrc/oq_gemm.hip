@@ -1,0 +1,317 @@
+// Fake-quant Linear / QuantMatMul GEMM for gfx950.
+//
+// Replaces F.linear at quantize/int_linear.py:62, torch.matmul / torch.bmm at quantize/int_matmul.py:41-43
+// and the dgrad / wgrad GEMMs their autograd produces.  One strided-batched kernel covers every operand
+// layout of forward and backward WITHOUT transposed copies:
+//     C[m][n] = alpha * sum_k A(m,k) * B(n,k) + bias[n]
+// where each operand is either k-contiguous (row-major [rows][k]) or k-strided ([k][rows]).
+//
+// bf16 path (production): 128x128x64 block tile, 4 waves (2x2), 64x64 per wave as 4x4
+// v_mfma_f32_16x16x32_bf16 tiles, f32 accumulate.  Global -> registers -> LDS staging, double-buffered,
+// one barrier per K-step, next tile's global loads in flight under the MFMAs.
+//   * k-contiguous tiles sit in LDS as [128 rows][64 k] (128-B rows), 16-B chunk index XOR-swizzled with
+//     (row>>1)&7 so every ds_read_b128 lane group covers 16 distinct slots (conflict-free).
+//   * k-strided tiles sit in LDS as stored ([64 k][128 rows], 256-B rows) and are read with
+//     ds_read_b64_tr_b16 (hardware transpose); 32-B chunk index XOR-swizzled with (k&3)|((k>>3)&1)<<2 so the 8
+//     k-rows a 32-lane half touches spread over all 64 banks.
+//   * operands are fed to the MFMA swapped (B as the A-operand) so each lane ends up holding 4 CONSECUTIVE
+//     output columns: the epilogue stores 8/16 B per lane with no shuffles.
+// f32 path (parity mode): exact f32 on v_mfma_f32_16x16x4_f32, 64x64x16 tile, scalar predicated loads: any
+// shape, any alignment; numerics = k-ordered fmaf chain.
+#include "oq_common.h"
+
+namespace {
+
+struct GemmP {
+    const void* a;
+    const void* b;
+    void* c;
+    const float* bias;
+    int64_t M, N, K, lda, ldb, ldc;
+    int a_kc, b_kc;
+    float alpha;
+    int64_t batch_i, sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
+    int tiles_n;
+};
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand per stage
+
+__device__ __forceinline__ int kstr_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// ---- global -> registers ---------------------------------------------------------------------------
+// KC tile: 128 rows x 64 k.  thread: chunk = tid&7 (16 B of k), rows tid>>3 + 32*p.
+// KS tile: 64 k-rows x 128 rows. thread: c16 = tid&15, k-rows tid>>4 + 16*p.
+template <bool KC>
+__device__ __forceinline__ void load_tile(const bf16_t* base, int64_t ld, int64_t i0, int64_t k0, int64_t I, int64_t K,
+                                          int tid, u32x4 (&r)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (KC) {
+            const int chunk = tid & 7, row = (tid >> 3) + 32 * p;
+            const int64_t i = i0 + row, k = k0 + chunk * 8;
+            if (i < I && k < K) v = *reinterpret_cast<const u32x4*>(base + i * ld + k);
+        } else {
+            const int c16 = tid & 15, kr = (tid >> 4) + 16 * p;
+            const int64_t k = k0 + kr, i = i0 + c16 * 8;
+            if (k < K && i < I) v = *reinterpret_cast<const u32x4*>(base + k * ld + i);
+        }
+        r[p] = v;
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void store_tile(char* lds, int tid, const u32x4 (&r)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int off;
+        if (KC) {
+            const int chunk = tid & 7, row = (tid >> 3) + 32 * p;
+            off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        } else {
+            const int c16 = tid & 15, kr = (tid >> 4) + 16 * p;
+            off = kr * 256 + ((((c16 >> 1) ^ kstr_f(kr))) << 5) + ((c16 & 1) << 4);
+        }
+        *reinterpret_cast<u32x4*>(lds + off) = r[p];
+    }
+}
+
+// fragment for the 16 rows starting at `row0` (multiple of 16, within the 128-row tile) and k-substep ks.
+// returns lane's 8 bf16: element j = X[row0 + (lane&15)][ks*32 + 8*(lane>>4) + j]
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int row0, int ks, int lane) {
+    if (KC) {
+        const int row = row0 + (lane & 15);
+        const int chunk = ks * 4 + (lane >> 4);
+        const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        return *reinterpret_cast<const bf16x8*>(lds + off);
+    } else {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int k = ks * 32 + 8 * g + q;
+        const int c32 = row0 >> 4;
+        const int off0 = k * 256 + ((c32 ^ kstr_f(k)) << 5) + pp * 8;
+        const int off1 = (k + 4) * 256 + ((c32 ^ kstr_f(k + 4)) << 5) + pp * 8;
+        typedef __attribute__((address_space(3))) s16x4 lds_s4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + off0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + off1));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool AKC, bool BKC, typename TOUT>
+__global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tile = blockIdx.x;
+    const int64_t m0 = (int64_t)(tile / p.tiles_n) * BM, n0 = (int64_t)(tile % p.tiles_n) * BN;
+    const int64_t bo = blockIdx.z / p.batch_i, bi = blockIdx.z % p.batch_i;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.a) + bo * p.sa_o + bi * p.sa_i;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.b) + bo * p.sb_o + bi * p.sb_i;
+    TOUT* C = reinterpret_cast<TOUT*>(p.c) + bo * p.sc_o + bi * p.sc_i;
+
+    f32x4 acc[4][4];   // [mt][nt], lane holds C[m = mt*16 + (lane&15)][n = nt*16 + (lane>>4)*4 + r]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra[4], rb[4];
+    const int64_t nt = (p.K + BK - 1) / BK;
+    load_tile<AKC>(A, p.lda, m0, 0, p.M, p.K, tid, ra);
+    load_tile<BKC>(B, p.ldb, n0, 0, p.N, p.K, tid, rb);
+    store_tile<AKC>(smem, tid, ra);
+    store_tile<BKC>(smem + TILE_BYTES, tid, rb);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) {
+            load_tile<AKC>(A, p.lda, m0, (t + 1) * BK, p.M, p.K, tid, ra);
+            load_tile<BKC>(B, p.ldb, n0, (t + 1) * BK, p.N, p.K, tid, rb);
+        }
+        const char* sa = smem + cur * 2 * TILE_BYTES;
+        const char* sb = sa + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = read_frag<AKC>(sa, wm * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = read_frag<BKC>(sb, wn * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    // swapped operands: D[row = n-sub][col = m-sub]
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            char* da = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            store_tile<AKC>(da, tid, ra);
+            store_tile<BKC>(da + TILE_BYTES, tid, rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- epilogue: lane holds 4 consecutive n for one m ------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;   // N % 4 == 0 is enforced on the host
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r] * p.alpha;
+                if (p.bias) v[r] += p.bias[n + r];
+            }
+            TOUT* dst = C + m * p.ldc + n;
+            if constexpr (sizeof(TOUT) == 4) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+                *reinterpret_cast<bf4*>(dst) = bf4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// exact f32 path
+// ---------------------------------------------------------------------------------------------------
+constexpr int FM = 64, FN = 64, FK = 16;
+
+template <typename TOUT>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
+    __shared__ float As[FK][FM + 1];
+    __shared__ float Bs[FK][FN + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int tile = blockIdx.x;
+    const int64_t m0 = (int64_t)(tile / p.tiles_n) * FM, n0 = (int64_t)(tile % p.tiles_n) * FN;
+    const int64_t bo = blockIdx.z / p.batch_i, bi = blockIdx.z % p.batch_i;
+    const float* A = reinterpret_cast<const float*>(p.a) + bo * p.sa_o + bi * p.sa_i;
+    const float* B = reinterpret_cast<const float*>(p.b) + bo * p.sb_o + bi * p.sb_i;
+    TOUT* C = reinterpret_cast<TOUT*>(p.c) + bo * p.sc_o + bi * p.sc_i;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t k0 = 0; k0 < p.K; k0 += FK) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + 256 * e;   // 0..1023
+            int kk, ii;
+            // pick the fast-varying index along the contiguous global dim
+            if (p.a_kc) { kk = idx & 15; ii = idx >> 4; } else { ii = idx & 63; kk = idx >> 6; }
+            {
+                const int64_t m = m0 + ii, k = k0 + kk;
+                float v = 0.f;
+                if (m < p.M && k < p.K) v = p.a_kc ? A[m * p.lda + k] : A[k * p.lda + m];
+                As[kk][ii] = v;
+            }
+            if (p.b_kc) { kk = idx & 15; ii = idx >> 4; } else { ii = idx & 63; kk = idx >> 6; }
+            {
+                const int64_t n = n0 + ii, k = k0 + kk;
+                float v = 0.f;
+                if (n < p.N && k < p.K) v = p.b_kc ? B[n * p.ldb + k] : B[k * p.ldb + n];
+                Bs[kk][ii] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < FK / 4; ++ks) {
+            const int k = ks * 4 + (lane >> 4);
+            float fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = As[k][wm * 32 + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = Bs[k][wn * 32 + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[row = (lane>>4)*4 + r][col = lane&15] with A rows = m, B cols = n
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t m = m0 + wm * 32 + i * 16 + (lane >> 4) * 4 + r;
+                const int64_t n = n0 + wn * 32 + j * 16 + (lane & 15);
+                if (m < p.M && n < p.N) {
+                    float v = acc[i][j][r] * p.alpha;
+                    if (p.bias) v += p.bias[n];
+                    C[m * p.ldc + n] = (TOUT)v;
+                }
+            }
+}
+
+}  // namespace
+
+extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias, int64_t M, int64_t N, int64_t K,
+                       int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
+                       float alpha, int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o,
+                       int64_t sb_i, int64_t sc_o, int64_t sc_i, void* stream) {
+    OQ_CHECK_ARG(a && bm && c, "oq_gemm: null operand");
+    OQ_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch_o > 0 && batch_i > 0, "oq_gemm: empty problem M=%lld N=%lld K=%lld",
+                 (long long)M, (long long)N, (long long)K);
+    OQ_CHECK_ARG(batch_o * batch_i <= 65535, "oq_gemm: batch %lld too large", (long long)(batch_o * batch_i));
+    OQ_CHECK_ARG(out_dtype == OQ_F32 || out_dtype == OQ_BF16, "oq_gemm: out dtype %d", out_dtype);
+    GemmP p{};
+    p.a = a; p.b = bm; p.c = c; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.a_kc = a_kc; p.b_kc = b_kc; p.alpha = alpha; p.batch_i = batch_i;
+    p.sa_o = sa_o; p.sa_i = sa_i; p.sb_o = sb_o; p.sb_i = sb_i; p.sc_o = sc_o; p.sc_i = sc_i;
+    hipStream_t st = (hipStream_t)stream;
+    if (in_dtype == OQ_BF16) {
+        // 16-byte vector loads / 8-16-byte stores
+        OQ_CHECK_ARG(oq_aligned16(a) && oq_aligned16(bm) && oq_aligned16(c), "oq_gemm(bf16): base pointers 16-B aligned");
+        OQ_CHECK_ARG(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "oq_gemm(bf16): lda/ldb %% 8, ldc %% 4");
+        OQ_CHECK_ARG(sa_o % 8 == 0 && sa_i % 8 == 0 && sb_o % 8 == 0 && sb_i % 8 == 0 && sc_o % 4 == 0 && sc_i % 4 == 0,
+                     "oq_gemm(bf16): batch strides must keep 16-B alignment");
+        OQ_CHECK_ARG((a_kc ? K : M) % 8 == 0 && (b_kc ? K : N) % 8 == 0 && N % 4 == 0,
+                     "oq_gemm(bf16): contiguous dims must be multiples of 8 (M=%lld N=%lld K=%lld)", (long long)M,
+                     (long long)N, (long long)K);
+        const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
+        p.tiles_n = (int)tn;
+        dim3 grid((unsigned)(tm * tn), 1, (unsigned)(batch_o * batch_i));
+#define LAUNCH_BF16(AK, BK_, T) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T>), grid, dim3(256), 0, st, p)
+        const int key = (a_kc ? 4 : 0) | (b_kc ? 2 : 0) | (out_dtype == OQ_F32 ? 1 : 0);
+        switch (key) {
+            case 0: LAUNCH_BF16(false, false, bf16_t); break;
+            case 1: LAUNCH_BF16(false, false, float); break;
+            case 2: LAUNCH_BF16(false, true, bf16_t); break;
+            case 3: LAUNCH_BF16(false, true, float); break;
+            case 4: LAUNCH_BF16(true, false, bf16_t); break;
+            case 5: LAUNCH_BF16(true, false, float); break;
+            case 6: LAUNCH_BF16(true, true, bf16_t); break;
+            case 7: LAUNCH_BF16(true, true, float); break;
+        }
+    } else if (in_dtype == OQ_F32) {
+        const int64_t tm = (M + FM - 1) / FM, tn = (N + FN - 1) / FN;
+        p.tiles_n = (int)tn;
+        dim3 grid((unsigned)(tm * tn), 1, (unsigned)(batch_o * batch_i));
+        if (out_dtype == OQ_F32)
+            hipLaunchKernelGGL((gemm_f32_kernel<float>), grid, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL((gemm_f32_kernel<bf16_t>), grid, dim3(256), 0, st, p);
+    } else {
+        oq_set_error("oq_gemm: in dtype %d unsupported", in_dtype);
+        return OQ_E_UNSUPPORTED;
+    }
+    OQ_CHECK_LAUNCH("oq_gemm");
+    return OQ_OK;
+}

@@ -1,0 +1,191 @@
+// OmniLlamaRMSNorm / OmniLayerNorm forward + backward for gfx950 (quantize/omni_norm.py:26-34,:52-63).
+// One workgroup per row (row kept in registers, <= 4 chunks of 8 per lane), f32 statistics.
+// Backward column sums (gw, gb) are accumulated in registers over the rows a workgroup walks and flushed with
+// one float atomic per column per workgroup.
+#include "oq_common.h"
+
+namespace {
+constexpr int MAXCH = 4;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    v = wave_sum(v);
+    if (nw == 1) return v;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float a = red[0];
+    for (int k = 1; k < nw; ++k) a += red[k];
+    return a;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) norm_fwd_kernel(const T* x, int64_t rows, int64_t cols, const float* w,
+                                                        const float* b, float eps, int ln, T* y, float* rstd_out,
+                                                        float* mean_out) {
+    __shared__ float red[16];
+    const int t = threadIdx.x, BT = blockDim.x;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        float v[MAXCH][8];
+        bool valid[MAXCH];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int64_t c0 = ((int64_t)j * BT + t) * 8;
+            valid[j] = c0 < cols;
+            if (valid[j]) {
+                Vec8<T>::load(x + r * cols + c0, v[j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += ln ? v[j][i] : v[j][i] * v[j][i];
+            }
+        }
+        s = block_sum(s, red);
+        float mean = 0.f, var;
+        if (ln) {
+            mean = s / (float)cols;
+            float s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j)
+                if (valid[j]) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float d = v[j][i] - mean; s2 += d * d; }
+                }
+            var = block_sum(s2, red) / (float)cols;
+        } else {
+            var = s / (float)cols;
+        }
+        const float rstd = rsqrtf(var + eps);
+        if (t == 0) {
+            rstd_out[r] = rstd;
+            if (mean_out) mean_out[r] = mean;
+        }
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            if (!valid[j]) continue;
+            const int64_t c0 = ((int64_t)j * BT + t) * 8;
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (v[j][i] - mean) * rstd;
+                o[i] = w[c0 + i] * xh + (b ? b[c0 + i] : 0.f);
+            }
+            Vec8<T>::store(y + r * cols + c0, o);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, int64_t rows, int64_t cols,
+                                                       const float* w, const float* rstd_in, const float* mean_in,
+                                                       int ln, T* gx, float* gw, float* gb) {
+    __shared__ float red[16];
+    const int t = threadIdx.x, BT = blockDim.x;
+    float aw[MAXCH][8], ab[MAXCH][8];
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { aw[j][i] = 0.f; ab[j][i] = 0.f; }
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float rstd = rstd_in[r];
+        const float mean = (ln && mean_in) ? mean_in[r] : 0.f;
+        float xh[MAXCH][8], gh[MAXCH][8];   // normalised x, and gy*w
+        bool valid[MAXCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int64_t c0 = ((int64_t)j * BT + t) * 8;
+            valid[j] = c0 < cols;
+            if (valid[j]) {
+                float g[8];
+                Vec8<T>::load(x + r * cols + c0, xh[j]);
+                Vec8<T>::load(gy + r * cols + c0, g);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    xh[j][i] = (xh[j][i] - mean) * rstd;
+                    aw[j][i] += g[i] * xh[j][i];
+                    ab[j][i] += g[i];
+                    gh[j][i] = g[i] * w[c0 + i];
+                    s1 += gh[j][i];
+                    s2 += gh[j][i] * xh[j][i];
+                }
+            }
+        }
+        s2 = block_sum(s2, red) / (float)cols;
+        s1 = ln ? block_sum(s1, red) / (float)cols : 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            if (!valid[j]) continue;
+            const int64_t c0 = ((int64_t)j * BT + t) * 8;
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (gh[j][i] - s1 - xh[j][i] * s2) * rstd;
+            Vec8<T>::store(gx + r * cols + c0, o);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int64_t c0 = ((int64_t)j * BT + t) * 8;
+        if (c0 < cols) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (gw) atomicAdd(gw + c0 + i, aw[j][i]);
+                if (gb) atomicAdd(gb + c0 + i, ab[j][i]);
+            }
+        }
+    }
+}
+
+int norm_threads(int64_t cols) {
+    const int64_t lanes = (cols + 7) / 8;
+    if (lanes <= 64) return 64;
+    if (lanes <= 128) return 128;
+    if (lanes <= 256) return 256;
+    if (cols <= 8 * 512 * MAXCH) return 512;
+    return 1024;
+}
+}  // namespace
+
+extern "C" int oq_norm_fwd(const void* x, int dtype, int64_t rows, int64_t cols, const float* w, const float* b,
+                           float eps, int is_layernorm, void* y, float* rstd, float* mean, void* stream) {
+    OQ_CHECK_ARG(x && y && w && rstd, "oq_norm_fwd: null pointer");
+    OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 1024 * MAXCH, "oq_norm_fwd: cols %lld", (long long)cols);
+    OQ_CHECK_ARG(!is_layernorm || mean, "oq_norm_fwd: layernorm needs mean buffer");
+    const int bt = norm_threads(cols);
+    const int64_t grid = rows < 8192 ? rows : 8192;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OQ_F32)
+        hipLaunchKernelGGL((norm_fwd_kernel<float>), dim3(grid), dim3(bt), 0, st, (const float*)x, rows, cols, w, b, eps,
+                           is_layernorm, (float*)y, rstd, mean);
+    else if (dtype == OQ_BF16)
+        hipLaunchKernelGGL((norm_fwd_kernel<bf16_t>), dim3(grid), dim3(bt), 0, st, (const bf16_t*)x, rows, cols, w, b, eps,
+                           is_layernorm, (bf16_t*)y, rstd, mean);
+    else {
+        oq_set_error("oq_norm_fwd: dtype %d", dtype);
+        return OQ_E_UNSUPPORTED;
+    }
+    OQ_CHECK_LAUNCH("oq_norm_fwd");
+    return OQ_OK;
+}
+
+extern "C" int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t rows, int64_t cols, const float* w,
+                           const float* rstd, const float* mean, int is_layernorm, void* gx, float* gw, float* gb,
+                           void* stream) {
+    OQ_CHECK_ARG(x && gy && gx && w && rstd, "oq_norm_bwd: null pointer");
+    OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 512 * MAXCH, "oq_norm_bwd: cols %lld", (long long)cols);
+    int bt = norm_threads(cols);
+    if (bt > 512) bt = 512;
+    const int64_t grid = rows < 512 ? rows : 512;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OQ_F32)
+        hipLaunchKernelGGL((norm_bwd_kernel<float>), dim3(grid), dim3(bt), 0, st, (const float*)x, (const float*)gy, rows,
+                           cols, w, rstd, mean, is_layernorm, (float*)gx, gw, gb);
+    else if (dtype == OQ_BF16)
+        hipLaunchKernelGGL((norm_bwd_kernel<bf16_t>), dim3(grid), dim3(bt), 0, st, (const bf16_t*)x, (const bf16_t*)gy,
+                           rows, cols, w, rstd, mean, is_layernorm, (bf16_t*)gx, gw, gb);
+    else {
+        oq_set_error("oq_norm_bwd: dtype %d", dtype);
+        return OQ_E_UNSUPPORTED;
+    }
+    OQ_CHECK_LAUNCH("oq_norm_bwd");
+    return OQ_OK;
+}

@@ -1,0 +1,508 @@
+// UniformAffineQuantizer on gfx950: dynamic min/max + LWC + fake-quant, fused with the LET weight
+// re-parameterisation.  Forward and closed-form backward.
+//
+// Replaces (reference, /root/reference): quantize/quantizer.py:15-19,84-105,122-147 and the weight side of
+// models/transformation.py:24-69.  HBM-bound: every matrix element is read ONCE (one workgroup owns a whole
+// row and keeps it in registers: <=4 chunks of 8 elements per lane), reduced with wave shuffles (+ LDS across
+// waves for whole-row segments), quantised and written once.  Column-wise LET gradients are accumulated in
+// registers across the rows a workgroup walks (lane -> column mapping is fixed) and flushed with one float
+// atomic per column per workgroup.
+#include "oq_common.h"
+
+namespace {
+
+constexpr int MAXCH = 4;   // chunks of 8 elements per thread
+
+struct FQ {
+    const void* w;
+    int64_t rows, cols, seg;
+    int nbits, symmetric;
+    const float *col_mul, *row_div, *row_mul, *shift, *up, *low;
+    // fwd
+    void* y;
+    float *scale, *zp, *xmin, *xmax, *wshift;
+    // bwd
+    const void* g;
+    const float* g_wshift;
+    float *g_up, *g_low;
+    void* gx;
+    float *g_col_mul, *g_shift, *g_row_div, *g_row_mul;
+};
+
+// block-wide reduction of up to 3 values; op: 0 sum, 1 max, 2 min.  All threads must call.
+template <int NV>
+__device__ __forceinline__ void block_reduce(float (&v)[NV], const int (&op)[NV], float* red /*[NV*16]*/) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = op[i] == 0 ? wave_sum(v[i]) : (op[i] == 1 ? wave_max(v[i]) : wave_min(v[i]));
+    }
+    if (nw == 1) return;
+    __syncthreads();   // protect `red` from the previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[i * 16 + wid] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float a = red[i * 16];
+        for (int k = 1; k < nw; ++k) {
+            float b = red[i * 16 + k];
+            a = op[i] == 0 ? a + b : (op[i] == 1 ? fmaxf(a, b) : fminf(a, b));
+        }
+        v[i] = a;
+    }
+}
+
+struct QP {
+    float s, z, su, sl, hi, lo;
+};
+
+__device__ __forceinline__ QP make_qp(float hi, float lo, const float* up, const float* low, int64_t sidx, int nbits,
+                                      int symmetric) {
+    QP q;
+    q.hi = hi;
+    q.lo = lo;
+    q.su = up ? sigmoidf_(up[sidx]) : 1.0f;
+    q.sl = low ? sigmoidf_(low[sidx]) : 1.0f;
+    const float hs = up ? q.su * hi : hi;
+    const float ls = low ? q.sl * lo : lo;
+    if (symmetric) {
+        const float lv = (float)((1 << (nbits - 1)) - 1);
+        float s = fmaxf(fabsf(hs), fabsf(ls)) / lv;
+        if (hs != hs || ls != ls) s = hs + ls;               // keep NaN
+        q.s = (s != s) ? s : fminf(fmaxf(s, 1e-5f), 1e4f);
+        q.z = lv;
+    } else {
+        const float Q = (float)((1 << nbits) - 1);
+        q.s = (hs - ls) / Q;                                 // not clamped: reference quirk Q1
+        float zp = -ls / q.s;
+        zp = (zp != zp) ? zp : fminf(fmaxf(zp, -1e4f), 1e4f);
+        q.z = rintf(zp);
+    }
+    return q;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+template <typename TIN, typename TOUT>
+__global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
+    __shared__ float red[3 * 16];
+    const int t = threadIdx.x, BT = blockDim.x;
+    const bool small = p.seg <= 512;
+    const int lps = small ? (int)(p.seg >> 3) : 64;
+    const int64_t nseg = p.cols / p.seg;
+    const float Q = (float)((1 << p.nbits) - 1);
+    const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
+    TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
+
+    for (int64_t r = blockIdx.x; r < p.rows; r += gridDim.x) {
+        float x[MAXCH][8];
+        bool valid[MAXCH];
+        float dot = 0.f;
+        const float rd = p.row_div ? p.row_div[r] : 1.f;
+        const float rm = p.row_mul ? p.row_mul[r] : 1.f;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int64_t c0 = ((int64_t)j * BT + t) * 8;
+            valid[j] = c0 < p.cols;
+            if (valid[j]) {
+                Vec8<TIN>::load(wbase + r * p.cols + c0, x[j]);
+                if (p.shift) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dot += x[j][i] * p.shift[c0 + i];
+                }
+                if (p.col_mul) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[j][i] = x[j][i] * p.col_mul[c0 + i];
+                }
+                if (p.row_div) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[j][i] = x[j][i] / rd;
+                }
+                if (p.row_mul) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[j][i] = x[j][i] * rm;
+                }
+            }
+        }
+        // ---- min / max (NaN-propagating like torch.amax/amin) ---------------------------------
+        float hi[MAXCH], lo[MAXCH], bad[MAXCH];
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            hi[j] = -INFINITY;
+            lo[j] = INFINITY;
+            bad[j] = 0.f;
+            if (valid[j]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    hi[j] = fmaxf(hi[j], x[j][i]);
+                    lo[j] = fminf(lo[j], x[j][i]);
+                    bad[j] = (x[j][i] != x[j][i]) ? 1.f : bad[j];
+                }
+            }
+        }
+        if (small) {
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j) {
+                hi[j] = wave_max(hi[j], lps);
+                lo[j] = wave_min(lo[j], lps);
+                bad[j] = wave_max(bad[j], lps);
+            }
+        } else {
+            float v[3] = {-INFINITY, INFINITY, 0.f};
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j) {
+                v[0] = fmaxf(v[0], hi[j]);
+                v[1] = fminf(v[1], lo[j]);
+                v[2] = fmaxf(v[2], bad[j]);
+            }
+            const int op[3] = {1, 2, 1};
+            block_reduce<3>(v, op, red);
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j) { hi[j] = v[0]; lo[j] = v[1]; bad[j] = v[2]; }
+        }
+        // ---- quantise ---------------------------------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            if (!valid[j]) continue;
+            const int64_t c0 = ((int64_t)j * BT + t) * 8;
+            const int64_t sidx = r * nseg + c0 / p.seg;
+            float h = hi[j], l = lo[j];
+            if (bad[j] != 0.f) { h = NAN; l = NAN; }
+            const QP q = make_qp(h, l, p.up, p.low, sidx, p.nbits, p.symmetric);
+            float yv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = rintf(x[j][i] / q.s) + q.z;
+                v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
+                yv[i] = (v - q.z) * q.s;
+            }
+            Vec8<TOUT>::store(ybase + r * p.cols + c0, yv);
+            const bool leader = small ? ((t & (lps - 1)) == 0) : (t == 0 && j == 0);
+            if (leader) {
+                if (p.scale) p.scale[sidx] = q.s;
+                if (p.zp) p.zp[sidx] = q.z;
+                if (p.xmin) p.xmin[sidx] = l;
+                if (p.xmax) p.xmax[sidx] = h;
+            }
+        }
+        if (p.wshift) {
+            float v[1] = {dot};
+            const int op[1] = {0};
+            block_reduce<1>(v, op, red);
+            if (t == 0) p.wshift[r] = v[0];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+template <typename TIN, typename TG, bool LET, int MAXT>
+__global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
+    __shared__ float red[3 * 16];
+    const int t = threadIdx.x, BT = blockDim.x;
+    const bool small = p.seg <= 512;
+    const int lps = small ? (int)(p.seg >> 3) : 64;
+    const int64_t nseg = p.cols / p.seg;
+    const float Q = (float)((1 << p.nbits) - 1);
+    const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
+    const TG* gbase = reinterpret_cast<const TG*>(p.g);
+    TG* gxbase = reinterpret_cast<TG*>(p.gx);
+    const bool need_let = LET && (p.g_col_mul || p.g_row_div || p.g_row_mul);
+    const bool need_gx = p.gx || need_let;
+    const bool need_sh = LET && p.g_shift;
+
+    constexpr int NACC = LET ? MAXCH : 1;
+    float acc_cm[NACC][8], acc_sh[NACC][8];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc_cm[j][i] = 0.f; acc_sh[j][i] = 0.f; }
+
+    for (int64_t r = blockIdx.x; r < p.rows; r += gridDim.x) {
+        float w[MAXCH][8], x[MAXCH][8], G[MAXCH][8];
+        bool valid[MAXCH];
+        const float rd = p.row_div ? p.row_div[r] : 1.f;
+        const float rm = p.row_mul ? p.row_mul[r] : 1.f;
+        const float gws = p.g_wshift ? p.g_wshift[r] : 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int64_t c0 = ((int64_t)j * BT + t) * 8;
+            valid[j] = c0 < p.cols;
+            if (valid[j]) {
+                Vec8<TIN>::load(wbase + r * p.cols + c0, w[j]);
+                Vec8<TG>::load(gbase + r * p.cols + c0, G[j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = w[j][i];
+                    if (p.col_mul) v = v * p.col_mul[c0 + i];
+                    if (p.row_div) v = v / rd;
+                    if (p.row_mul) v = v * rm;
+                    x[j][i] = v;
+                }
+            }
+        }
+        float hi[MAXCH], lo[MAXCH];
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            hi[j] = -INFINITY;
+            lo[j] = INFINITY;
+            if (valid[j]) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { hi[j] = fmaxf(hi[j], x[j][i]); lo[j] = fminf(lo[j], x[j][i]); }
+            }
+        }
+        if (small) {
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j) { hi[j] = wave_max(hi[j], lps); lo[j] = wave_min(lo[j], lps); }
+        } else {
+            float v[2] = {-INFINITY, INFINITY};
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j) { v[0] = fmaxf(v[0], hi[j]); v[1] = fminf(v[1], lo[j]); }
+            const int op[2] = {1, 2};
+            block_reduce<2>(v, op, red);
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j) { hi[j] = v[0]; lo[j] = v[1]; }
+        }
+        // ---- gs = sum G * d y/d s ; tie counts -------------------------------------------------
+        QP qp[MAXCH];
+        float gs[MAXCH], nhi[MAXCH], nlo[MAXCH];
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            gs[j] = 0.f; nhi[j] = 0.f; nlo[j] = 0.f;
+            if (valid[j]) {
+                const int64_t c0 = ((int64_t)j * BT + t) * 8;
+                qp[j] = make_qp(hi[j], lo[j], p.up, p.low, r * nseg + c0 / p.seg, p.nbits, p.symmetric);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float tq = x[j][i] / qp[j].s;
+                    const float v = rintf(tq) + qp[j].z;
+                    const bool in = (v >= 0.f) && (v <= Q);
+                    const float qv = fminf(fmaxf(v, 0.f), Q);
+                    gs[j] += G[j][i] * ((qv - qp[j].z) - (in ? tq : 0.f));
+                    nhi[j] += (x[j][i] == hi[j]) ? 1.f : 0.f;
+                    nlo[j] += (x[j][i] == lo[j]) ? 1.f : 0.f;
+                }
+            }
+        }
+        if (small) {
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j) {
+                gs[j] = wave_sum(gs[j], lps);
+                nhi[j] = wave_sum(nhi[j], lps);
+                nlo[j] = wave_sum(nlo[j], lps);
+            }
+        } else {
+            float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j) { v[0] += gs[j]; v[1] += nhi[j]; v[2] += nlo[j]; }
+            const int op[3] = {0, 0, 0};
+            block_reduce<3>(v, op, red);
+#pragma unroll
+            for (int j = 0; j < MAXCH; ++j) { gs[j] = v[0]; nhi[j] = v[1]; nlo[j] = v[2]; }
+        }
+        // ---- d s / d hi', d s / d lo'  (hi' = su*hi, lo' = sl*lo) --------------------------------
+        float acc_rd = 0.f, acc_rm = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            if (!valid[j]) continue;
+            const int64_t c0 = ((int64_t)j * BT + t) * 8;
+            const int64_t sidx = r * nseg + c0 / p.seg;
+            const QP q = qp[j];
+            float ds_dhs, ds_dls;   // d scale / d hi', d scale / d lo'
+            if (p.symmetric) {
+                const float lv = (float)((1 << (p.nbits - 1)) - 1);
+                const float hs = q.su * q.hi, ls = q.sl * q.lo;
+                const float a = fabsf(hs), b = fabsf(ls);
+                const float raw = fmaxf(a, b) / lv;
+                const float pass = (raw >= 1e-5f && raw <= 1e4f) ? 1.f : 0.f;
+                const float sh = hs > 0.f ? 1.f : (hs < 0.f ? -1.f : 0.f);
+                const float sg = ls > 0.f ? 1.f : (ls < 0.f ? -1.f : 0.f);
+                const float wa = a > b ? 1.f : (a == b ? 0.5f : 0.f);
+                ds_dhs = pass * wa * sh / lv;
+                ds_dls = pass * (1.f - wa) * sg / lv;
+            } else {
+                ds_dhs = 1.f / Q;
+                ds_dls = -1.f / Q;
+            }
+            const float g_hs = gs[j] * ds_dhs;   // dL/d hi'
+            const float g_ls = gs[j] * ds_dls;   // dL/d lo'
+            const bool leader = small ? ((t & (lps - 1)) == 0) : (t == 0 && j == 0);
+            if (leader) {
+                if (p.g_up) p.g_up[sidx] = g_hs * q.hi * q.su * (1.f - q.su);
+                if (p.g_low) p.g_low[sidx] = g_ls * q.lo * q.sl * (1.f - q.sl);
+            }
+            if (need_gx || need_sh) {
+                float gxv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float tq = x[j][i] / q.s;
+                    const float v = rintf(tq) + q.z;
+                    const bool in = (v >= 0.f) && (v <= Q);
+                    float gv = in ? G[j][i] : 0.f;
+                    if (x[j][i] == q.hi) gv += g_hs * q.su / nhi[j];
+                    if (x[j][i] == q.lo) gv += g_ls * q.sl / nlo[j];
+                    gxv[i] = gv;
+                    if constexpr (LET) {
+                      if (need_let) {
+                        // x = ((w*cm)/rd)*rm ; b = (w*cm)/rd
+                        float a = w[j][i];
+                        if (p.col_mul) a = a * p.col_mul[c0 + i];
+                        const float b = p.row_div ? a / rd : a;
+                        acc_rm += gv * b;
+                        const float gb = p.row_mul ? gv * rm : gv;
+                        acc_rd += gb * (-b / rd);
+                        const float ga = p.row_div ? gb / rd : gb;
+                        acc_cm[j][i] += ga * w[j][i];
+                      }
+                      if (need_sh) acc_sh[j][i] += gws * w[j][i];
+                    }
+                }
+                if (p.gx) Vec8<TG>::store(gxbase + r * p.cols + c0, gxv);
+            }
+        }
+        if (p.g_row_div || p.g_row_mul) {
+            float v[2] = {acc_rd, acc_rm};
+            const int op[2] = {0, 0};
+            block_reduce<2>(v, op, red);
+            if (t == 0) {
+                if (p.g_row_div) p.g_row_div[r] = v[0];
+                if (p.g_row_mul) p.g_row_mul[r] = v[1];
+            }
+        }
+    }
+    if constexpr (LET) {
+      if (p.g_col_mul || p.g_shift) {
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int64_t c0 = ((int64_t)j * BT + t) * 8;
+            if (c0 < p.cols) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (p.g_col_mul) atomicAdd(p.g_col_mul + c0 + i, acc_cm[j][i]);
+                    if (p.g_shift) atomicAdd(p.g_shift + c0 + i, acc_sh[j][i]);
+                }
+            }
+        }
+      }
+    }
+}
+
+int block_threads(int64_t cols) {
+    const int64_t lanes = (cols + 7) / 8;   // lanes needed with one chunk each
+    if (lanes <= 64) return 64;
+    if (lanes <= 128) return 128;
+    if (cols <= 8 * 256 * MAXCH) return 256;
+    if (cols <= 8 * 512 * MAXCH) return 512;
+    return 1024;
+}
+
+int check_shape(const char* fn, int64_t rows, int64_t cols, int64_t seg, int nbits) {
+    OQ_CHECK_ARG(rows > 0 && cols > 0 && seg > 0, "%s: empty shape rows=%lld cols=%lld seg=%lld", fn, (long long)rows,
+                 (long long)cols, (long long)seg);
+    OQ_CHECK_ARG(nbits >= 2 && nbits < 16, "%s: bitwidth %d not supported (2..15)", fn, nbits);
+    OQ_CHECK_ARG(cols % seg == 0, "%s: cols %lld not a multiple of seg %lld (ragged groups unsupported)", fn,
+                 (long long)cols, (long long)seg);
+    OQ_CHECK_ARG(seg % 8 == 0, "%s: seg %lld must be a multiple of 8", fn, (long long)seg);
+    if (seg <= 512) {
+        const int64_t l = seg / 8;
+        OQ_CHECK_ARG((l & (l - 1)) == 0, "%s: seg/8 = %lld must be a power of two when seg <= 512", fn, (long long)l);
+    } else {
+        OQ_CHECK_ARG(seg == cols, "%s: seg %lld > 512 must equal cols %lld", fn, (long long)seg, (long long)cols);
+    }
+    OQ_CHECK_ARG(cols <= 8 * 1024 * MAXCH, "%s: cols %lld exceeds %d", fn, (long long)cols, 8 * 1024 * MAXCH);
+    return OQ_OK;
+}
+
+}  // namespace
+
+#define FQ_DISPATCH_FWD(TIN, TOUT) \
+    hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p)
+
+extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits,
+                                int symmetric, const float* col_mul, const float* row_div, const float* row_mul,
+                                const float* shift, const float* up, const float* low, void* y, int y_dtype,
+                                float* scale, float* zp, float* xmin, float* xmax, float* wshift, void* stream) {
+    int rc = check_shape("oq_fakequant_fwd", rows, cols, seg, nbits);
+    if (rc) return rc;
+    OQ_CHECK_ARG(w && y, "oq_fakequant_fwd: null w/y");
+    OQ_CHECK_ARG(oq_aligned16(w) && oq_aligned16(y), "oq_fakequant_fwd: w/y must be 16-byte aligned");
+    OQ_CHECK_ARG((up == nullptr) == (low == nullptr), "oq_fakequant_fwd: up/low must both be given or both NULL");
+    OQ_CHECK_ARG(!wshift || shift, "oq_fakequant_fwd: wshift requested without shift");
+    FQ p{};
+    p.w = w; p.rows = rows; p.cols = cols; p.seg = seg; p.nbits = nbits; p.symmetric = symmetric;
+    p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = wshift ? shift : nullptr;
+    p.up = up; p.low = low; p.y = y; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax; p.wshift = wshift;
+    const int bt = block_threads(cols);
+    const int64_t grid = rows < 8192 ? rows : 8192;
+    const int key = w_dtype * 3 + y_dtype;
+    switch (key) {
+        case OQ_F32 * 3 + OQ_F32: FQ_DISPATCH_FWD(float, float); break;
+        case OQ_F32 * 3 + OQ_BF16: FQ_DISPATCH_FWD(float, bf16_t); break;
+        case OQ_F16 * 3 + OQ_F32: FQ_DISPATCH_FWD(f16_t, float); break;
+        case OQ_F16 * 3 + OQ_BF16: FQ_DISPATCH_FWD(f16_t, bf16_t); break;
+        case OQ_F16 * 3 + OQ_F16: FQ_DISPATCH_FWD(f16_t, f16_t); break;
+        case OQ_BF16 * 3 + OQ_BF16: FQ_DISPATCH_FWD(bf16_t, bf16_t); break;
+        case OQ_BF16 * 3 + OQ_F32: FQ_DISPATCH_FWD(bf16_t, float); break;
+        default:
+            oq_set_error("oq_fakequant_fwd: unsupported dtype pair in=%d out=%d", w_dtype, y_dtype);
+            return OQ_E_UNSUPPORTED;
+    }
+    OQ_CHECK_LAUNCH("oq_fakequant_fwd");
+    return OQ_OK;
+}
+
+#define FQ_DISPATCH_BWD(TIN, TG)                                                                                  \
+    do {                                                                                                          \
+        if (bt > 512)                                                                                             \
+            hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, true, 1024>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);  \
+        else if (let)                                                                                             \
+            hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, true, 512>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);   \
+        else                                                                                                      \
+            hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, false, 512>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);  \
+    } while (0)
+
+extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits,
+                                int symmetric, const float* col_mul, const float* row_div, const float* row_mul,
+                                const float* shift, const float* up, const float* low, const void* g, int g_dtype,
+                                const float* g_wshift, float* g_up, float* g_low, void* gx, int gx_dtype,
+                                float* g_col_mul, float* g_shift, float* g_row_div, float* g_row_mul, void* stream) {
+    int rc = check_shape("oq_fakequant_bwd", rows, cols, seg, nbits);
+    if (rc) return rc;
+    OQ_CHECK_ARG(w && g, "oq_fakequant_bwd: null w/g");
+    OQ_CHECK_ARG(oq_aligned16(w) && oq_aligned16(g) && oq_aligned16(gx), "oq_fakequant_bwd: 16-byte alignment");
+    OQ_CHECK_ARG(!gx || gx_dtype == g_dtype, "oq_fakequant_bwd: gx dtype must equal g dtype");
+    OQ_CHECK_ARG((up == nullptr) == (low == nullptr), "oq_fakequant_bwd: up/low must both be given or both NULL");
+    OQ_CHECK_ARG(!g_shift || g_wshift, "oq_fakequant_bwd: g_shift needs g_wshift");
+    OQ_CHECK_ARG(!g_col_mul || col_mul, "oq_fakequant_bwd: g_col_mul needs col_mul");
+    OQ_CHECK_ARG(!g_row_div || row_div, "oq_fakequant_bwd: g_row_div needs row_div");
+    OQ_CHECK_ARG(!g_row_mul || row_mul, "oq_fakequant_bwd: g_row_mul needs row_mul");
+    FQ p{};
+    p.w = w; p.rows = rows; p.cols = cols; p.seg = seg; p.nbits = nbits; p.symmetric = symmetric;
+    p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = shift; p.up = up; p.low = low;
+    p.g = g; p.g_wshift = g_wshift; p.g_up = g_up; p.g_low = g_low; p.gx = gx;
+    p.g_col_mul = g_col_mul; p.g_shift = g_shift; p.g_row_div = g_row_div; p.g_row_mul = g_row_mul;
+    const int bt = block_threads(cols);
+    // column accumulators are flushed once per workgroup: keep the grid small when they are live
+    const int64_t cap = (g_col_mul || g_shift) ? 1024 : 8192;
+    const int64_t grid = rows < cap ? rows : cap;
+    const bool let = g_col_mul || g_shift || g_row_div || g_row_mul;
+    const int key = w_dtype * 3 + g_dtype;
+    switch (key) {
+        case OQ_F32 * 3 + OQ_F32: FQ_DISPATCH_BWD(float, float); break;
+        case OQ_F32 * 3 + OQ_BF16: FQ_DISPATCH_BWD(float, bf16_t); break;
+        case OQ_F16 * 3 + OQ_F32: FQ_DISPATCH_BWD(f16_t, float); break;
+        case OQ_F16 * 3 + OQ_BF16: FQ_DISPATCH_BWD(f16_t, bf16_t); break;
+        case OQ_BF16 * 3 + OQ_BF16: FQ_DISPATCH_BWD(bf16_t, bf16_t); break;
+        case OQ_BF16 * 3 + OQ_F32: FQ_DISPATCH_BWD(bf16_t, float); break;
+        default:
+            oq_set_error("oq_fakequant_bwd: unsupported dtype pair w=%d g=%d", w_dtype, g_dtype);
+            return OQ_E_UNSUPPORTED;
+    }
+    OQ_CHECK_LAUNCH("oq_fakequant_bwd");
+    return OQ_OK;
+}

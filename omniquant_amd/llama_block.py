@@ -1,0 +1,143 @@
+"""Quantised LLaMA decoder block on the HIP path.  Surface = reference models/int_llama_layer.py.
+
+Data layout: projections produce [bs, T, heads*hd]; q/k/v stay in that head-interleaved layout (viewed as
+[bs, T, heads, hd]) through RoPE, head-wise fake-quant and both attention GEMMs (strided-batched, no
+transposes).  GQA (num_key_value_heads < num_attention_heads) is handled by the GEMM's zero batch stride.
+"""
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .block_common import QuantBlockMixin
+from .linear import QuantLinear
+from .matmul import QuantMatMul
+from .norm import OmniLlamaRMSNorm
+
+
+def _rope_theta(config):
+    rp = getattr(config, "rope_parameters", None)
+    if isinstance(rp, dict) and "rope_theta" in rp:
+        return float(rp["rope_theta"])
+    return float(getattr(config, "rope_theta", 10000.0))
+
+
+class QuantLlamaMLP(nn.Module):
+    def __init__(self, org_module: nn.Module, hidden_size: int, intermediate_size: int, hidden_act: str, args=None):
+        super().__init__()
+        self.gate_proj = QuantLinear(org_module.gate_proj, args.weight_quant_params, args.act_quant_params)
+        self.down_proj = QuantLinear(org_module.down_proj, args.weight_quant_params, args.act_quant_params)
+        self.up_proj = QuantLinear(org_module.up_proj, args.weight_quant_params, args.act_quant_params)
+        if hidden_act not in ("silu", "swish"):
+            raise NotImplementedError(f"hidden_act {hidden_act}: only SiLU has a HIP kernel")
+
+    def forward(self, x):
+        return self.down_proj(ops.SiluMulFn.apply(self.gate_proj(x), self.up_proj(x)))
+
+
+class QuantLlamaAttention(nn.Module):
+    def __init__(self, org_module: nn.Module, config, args=None):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = getattr(config, "num_key_value_heads", None) or self.num_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        self.max_position_embeddings = config.max_position_embeddings
+        if (self.head_dim * self.num_heads) != self.hidden_size:
+            raise ValueError(f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size}"
+                             f" and `num_heads`: {self.num_heads}).")
+        self.rope_theta = _rope_theta(config)
+        self._rope_cache = None
+        self.k_proj = QuantLinear(org_module.k_proj, args.weight_quant_params, args.act_quant_params)
+        self.v_proj = QuantLinear(org_module.v_proj, args.weight_quant_params, args.act_quant_params)
+        self.q_proj = QuantLinear(org_module.q_proj, args.weight_quant_params, args.act_quant_params)
+        self.o_proj = QuantLinear(org_module.o_proj, args.weight_quant_params, args.act_quant_params)
+        self.qkt_matmul = QuantMatMul(args.q_quant_params, args.k_quant_params, matmul_func=torch.matmul)
+        self.pv_matmul = QuantMatMul(args.p_quant_params, args.v_quant_params, matmul_func=torch.matmul)
+        self.use_weight_quant = False
+        self.use_act_quant = False
+
+    def _rope_tables(self, position_ids, T, device):
+        """cos/sin [T, hd] f32 gathered by position_ids (transformers-4.31 LlamaRotaryEmbedding formula)."""
+        key = (T, str(device), None if position_ids is None else position_ids.data_ptr())
+        if self._rope_cache is not None and self._rope_cache[0] == key:
+            return self._rope_cache[1], self._rope_cache[2]
+        hd = self.head_dim
+        inv = 1.0 / (self.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32, device=device) / hd))
+        pos = torch.arange(T, dtype=torch.float32, device=device) if position_ids is None else \
+            position_ids.reshape(-1)[:T].to(device=device, dtype=torch.float32)
+        fr = torch.outer(pos, inv)
+        emb = torch.cat((fr, fr), dim=-1)
+        cos, sin = emb.cos().contiguous(), emb.sin().contiguous()
+        self._rope_cache = (key, cos, sin)
+        return cos, sin
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
+                output_attentions=False, use_cache=False):
+        if past_key_value is not None or use_cache or output_attentions:
+            raise NotImplementedError("the calibration hot path runs without KV cache / attention outputs")
+        bsz, q_len, _ = hidden_states.size()
+        nh, nkv, hd = self.num_heads, self.num_key_value_heads, self.head_dim
+        q = self.q_proj(hidden_states).view(bsz, q_len, nh, hd)
+        k = self.k_proj(hidden_states).view(bsz, q_len, nkv, hd)
+        v = self.v_proj(hidden_states).view(bsz, q_len, nkv, hd)
+        cos, sin = self._rope_tables(position_ids, q_len, hidden_states.device)
+        q = ops.RopeFn.apply(q, cos, sin)
+        k = ops.RopeFn.apply(k, cos, sin)
+        # head-wise (per head, per token) fake quant over head_dim; repeat_kv commutes with it
+        q = self.qkt_matmul.quant_x1(q)
+        k = self.qkt_matmul.quant_x2(k)
+        scores = self.qkt_matmul.scores(q, k)                       # [bs, nh, T, T], unscaled
+        mask = None
+        if attention_mask is not None:
+            if attention_mask.size() != (bsz, 1, q_len, q_len):
+                raise ValueError(f"Attention mask should be of size {(bsz, 1, q_len, q_len)}, but is "
+                                 f"{attention_mask.size()}")
+            mask = attention_mask[0, 0]
+        probs = ops.SoftmaxFn.apply(scores, mask, 1.0 / math.sqrt(hd))   # scale, +mask, clamp, f32 softmax
+        probs = self.pv_matmul.quant_x1(probs)
+        v = self.pv_matmul.quant_x2(v)
+        attn = self.pv_matmul.apply_probs(probs, v)                # [bs, T, nh, hd]
+        attn = self.o_proj(attn.view(bsz, q_len, self.hidden_size))
+        return attn, None, None
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant = weight_quant
+        self.use_act_quant = act_quant
+        for m in self.modules():
+            if isinstance(m, (QuantLinear, QuantMatMul)):
+                m.set_quant_state(weight_quant, act_quant)
+
+
+class QuantLlamaDecoderLayer(QuantBlockMixin, nn.Module):
+    def __init__(self, config, ori_layer, args):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.self_attn = QuantLlamaAttention(org_module=ori_layer.self_attn, config=config, args=args)
+        self.mlp = QuantLlamaMLP(org_module=ori_layer.mlp, hidden_size=self.hidden_size,
+                                 intermediate_size=config.intermediate_size, hidden_act=config.hidden_act, args=args)
+        self.input_layernorm = OmniLlamaRMSNorm(ori_layer.input_layernorm, eps=ori_layer.input_layernorm.variance_epsilon)
+        self.post_attention_layernorm = OmniLlamaRMSNorm(ori_layer.post_attention_layernorm,
+                                                         eps=ori_layer.post_attention_layernorm.variance_epsilon)
+
+    def _let_names(self):
+        a, m = self.self_attn, self.mlp
+        return dict(q=a.q_proj, k=a.k_proj, v=a.v_proj, o=a.o_proj, fc1=[m.up_proj, m.gate_proj], last=m.down_proj,
+                    ln1=self.input_layernorm, ln2=self.post_attention_layernorm)
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
+                output_attentions=False, use_cache=False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        residual = hidden_states
+        h = self.input_layernorm(hidden_states)
+        h, _, _ = self.self_attn(hidden_states=h, attention_mask=attention_mask, position_ids=position_ids,
+                                 past_key_value=past_key_value, output_attentions=output_attentions, use_cache=use_cache)
+        hidden_states = ops.AddFn.apply(residual, h)
+        residual = hidden_states
+        h = self.post_attention_layernorm(hidden_states)
+        h = self.mlp(h)
+        hidden_states = ops.AddFn.apply(residual, h)
+        return (hidden_states,)

@@ -1,0 +1,45 @@
+"""OmniLayerNorm / OmniLlamaRMSNorm on the HIP path.  Surface = reference quantize/omni_norm.py:11-63."""
+import torch.nn as nn
+
+from . import ops
+
+
+class OmniLayerNorm(nn.Module):
+    def __init__(self, ori_layer_norm) -> None:
+        super().__init__()
+        self.use_act_quant = True
+        self.register_buffer("weight", ori_layer_norm.weight)
+        if ori_layer_norm.bias is not None:
+            self.register_buffer("bias", ori_layer_norm.bias)
+        else:
+            self.bias = None
+        self.eps = ori_layer_norm.eps
+        self.norm_func = ops.NormFn.apply
+        self.normalized_shape = ori_layer_norm.normalized_shape
+        self.use_temporary_parameter = False
+
+    def forward(self, x):
+        if self.use_temporary_parameter:
+            weight, bias = self.temp_weight, self.temp_bias
+        else:
+            weight, bias = self.weight, self.bias
+        return ops.NormFn.apply(x, weight, bias, self.eps, True)
+
+    def set_quant_state(self, use_weight_quant, use_act_quant):
+        self.use_act_quant = use_act_quant
+
+
+class OmniLlamaRMSNorm(nn.Module):
+    def __init__(self, ori_norm, eps=1e-6):
+        super().__init__()
+        self.register_buffer("weight", ori_norm.weight)
+        self.bias = None
+        self.variance_epsilon = eps
+        self.use_temporary_parameter = False
+
+    def forward(self, hidden_states):
+        if self.use_temporary_parameter:
+            weight, bias = self.temp_weight, self.temp_bias
+        else:
+            weight, bias = self.weight, self.bias if hasattr(self, "bias") else None
+        return ops.NormFn.apply(hidden_states, weight, bias, self.variance_epsilon, False)

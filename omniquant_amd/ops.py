@@ -1,0 +1,441 @@
+"""torch.autograd.Function wrappers around the C ABI (include/oq_hip.h).
+
+Each Function's forward AND backward are hand-written HIP kernels; PyTorch only allocates the outputs and keeps
+the graph.  Activations are float32 (parity mode: exact-f32 MFMA) or bfloat16 (production: bf16 MFMA).
+"""
+import math
+
+import torch
+
+from . import _capi as C
+
+
+def _empty_like(t, dtype=None):
+    return torch.empty(t.shape, dtype=dtype or t.dtype, device=t.device)
+
+
+def _f32(t):
+    """float32 contiguous view/copy of a small parameter vector (plumbing)."""
+    if t is None:
+        return None
+    t = t.detach() if not t.requires_grad else t
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------------
+# UniformAffineQuantizer core (+ LET weight re-parameterisation)
+# ------------------------------------------------------------------------------------------------------
+class FakeQuantFn(torch.autograd.Function):
+    """y = fake_quant(((w*col_mul)/row_div)*row_mul) over segments of `seg`; wshift = w @ shift.
+
+    Reference: quantize/quantizer.py:84-147 and models/transformation.py:24-69.  `stash` (dict) receives the
+    non-differentiable side outputs 'scale' and 'zp' ([rows*cols/seg, 1] f32)."""
+
+    @staticmethod
+    def forward(ctx, w, col_mul, row_div, row_mul, shift, up, low, nbits, seg, symmetric, out_dtype, stash):
+        w = w.contiguous()
+        cols = w.shape[-1]
+        rows = w.numel() // cols
+        nseg = rows * (cols // seg)
+        y = torch.empty(w.shape, dtype=out_dtype, device=w.device)
+        scale = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
+        zp = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
+        wshift = torch.empty((rows,), dtype=torch.float32, device=w.device) if shift is not None else None
+        cm, rd, rm, sh, u, l = (_f32(t) for t in (col_mul, row_div, row_mul, shift, up, low))
+        C.call("oq_fakequant_fwd", C.ptr(w), C.dt(w), rows, cols, seg, nbits, int(symmetric),
+               C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l),
+               C.ptr(y), C._DT[out_dtype], C.fptr(scale), C.fptr(zp), None, None, C.fptr(wshift), C.stream())
+        if stash is not None:
+            stash["scale"], stash["zp"] = scale, zp
+        ctx.save_for_backward(w, cm, rd, rm, sh, u, l)
+        ctx.cfg = (rows, cols, seg, nbits, int(symmetric))
+        if wshift is None:
+            wshift = torch.zeros((), device=w.device)   # placeholder output, never used
+            ctx.has_wshift = False
+        else:
+            ctx.has_wshift = True
+        ctx.mark_non_differentiable(*([] if ctx.has_wshift else [wshift]))
+        return y, wshift
+
+    @staticmethod
+    def backward(ctx, gy, gwshift):
+        w, cm, rd, rm, sh, u, l = ctx.saved_tensors
+        rows, cols, seg, nbits, symmetric = ctx.cfg
+        need = ctx.needs_input_grad   # w, col_mul, row_div, row_mul, shift, up, low
+        dev = w.device
+        if gy is None:
+            gy = torch.zeros(w.shape, dtype=torch.float32, device=dev)
+        gy = gy.contiguous()
+        nseg = rows * (cols // seg)
+        g_up = torch.empty((nseg, 1), dtype=torch.float32, device=dev) if need[5] else None
+        g_low = torch.empty((nseg, 1), dtype=torch.float32, device=dev) if need[6] else None
+        gx = torch.empty(w.shape, dtype=gy.dtype, device=dev) if need[0] else None
+        g_cm = torch.zeros((cols,), dtype=torch.float32, device=dev) if need[1] else None
+        g_rd = torch.empty((rows,), dtype=torch.float32, device=dev) if need[2] else None
+        g_rm = torch.empty((rows,), dtype=torch.float32, device=dev) if need[3] else None
+        g_sh = None
+        gws = None
+        if need[4] and ctx.has_wshift:
+            g_sh = torch.zeros((cols,), dtype=torch.float32, device=dev)
+            gws = gwshift.contiguous().float() if gwshift is not None else torch.zeros((rows,), device=dev)
+        C.call("oq_fakequant_bwd", C.ptr(w), C.dt(w), rows, cols, seg, nbits, symmetric,
+               C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l),
+               C.ptr(gy), C.dt(gy), C.fptr(gws), C.fptr(g_up), C.fptr(g_low), C.ptr(gx), C.dt(gy),
+               C.fptr(g_cm), C.fptr(g_sh), C.fptr(g_rd), C.fptr(g_rm), C.stream())
+        if gx is not None and gx.dtype != w.dtype:
+            gx = gx.to(w.dtype)
+        return gx, g_cm, g_rd, g_rm, g_sh, g_up, g_low, None, None, None, None, None
+
+
+def fake_quant(x, nbits, seg=None, up=None, low=None, symmetric=False, out_dtype=None, stash=None,
+               col_mul=None, row_div=None, row_mul=None, shift=None):
+    """Functional entry: returns y (and wshift when `shift` is given)."""
+    seg = seg or x.shape[-1]
+    y, wshift = FakeQuantFn.apply(x, col_mul, row_div, row_mul, shift, up, low, nbits, seg, symmetric,
+                                  out_dtype or x.dtype, stash)
+    return (y, wshift) if shift is not None else y
+
+
+# ------------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------------
+def gemm(a, b, c, M, N, K, lda, ldb, ldc, a_kc, b_kc, bias=None, alpha=1.0, batch_o=1, batch_i=1,
+         sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0):
+    """Raw strided-batched GEMM on device buffers (element offsets/strides)."""
+    for t in (a, b, c):
+        if not t.is_cuda:
+            raise C.OQError("gemm: the HIP path needs GPU tensors; there is no CPU fallback")
+        if not t.is_contiguous():
+            raise C.OQError("gemm: non-contiguous buffer")
+    es_in, es_out = a.element_size(), c.element_size()
+    C.call("oq_gemm", a.data_ptr() + a_off * es_in, b.data_ptr() + b_off * es_in, c.data_ptr() + c_off * es_out,
+           C.fptr(bias), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc), C.dt(a), C.dt(c), float(alpha),
+           batch_o, batch_i, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], C.stream())
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ wq.T + bias  (quantize/int_linear.py:62) with dgrad / wgrad / bias-grad kernels."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bias):
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        wq = wq.contiguous()
+        T, K = x2.shape
+        N = wq.shape[0]
+        if wq.dtype != x2.dtype:
+            raise C.OQError(f"LinearFn: weight dtype {wq.dtype} != activation dtype {x2.dtype}")
+        y = torch.empty((T, N), dtype=x2.dtype, device=x2.device)
+        b32 = _f32(bias)
+        gemm(x2, wq, y, T, N, K, K, K, N, True, True, bias=b32)
+        ctx.save_for_backward(x2, wq)
+        ctx.has_bias = bias is not None
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, wq = ctx.saved_tensors
+        T, K = x2.shape
+        N = wq.shape[0]
+        gy2 = gy.contiguous().view(T, N)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((T, K), dtype=x2.dtype, device=x2.device)
+            # dX[t,k] = sum_n dY[t,n] * W[n,k]   (B is k-strided: B(k_out, n) = W[n*K + k_out])
+            gemm(gy2, wq, gx, T, K, N, N, K, K, True, False)
+            gx = gx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty((N, K), dtype=wq.dtype, device=x2.device)
+            # dW[n,k] = sum_t dY[t,n] * X[t,k]   (both operands k-strided)
+            gemm(gy2, x2, gw, N, K, T, N, K, K, False, False)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty((N,), dtype=torch.float32, device=x2.device)
+            C.call("oq_colsum", C.ptr(gy2), C.dt(gy2), T, N, C.fptr(gb), C.stream())
+        return gx, gw, gb
+
+
+class AttnScoresFn(torch.autograd.Function):
+    """S[b,h] = Q[b,:,h,:] @ K[b,:,h//rep,:]^T  (quantize/int_matmul.py:41-43 as used at
+    models/int_llama_layer.py:143).  q [bs,T,nh,hd], k [bs,Tk,nkv,hd] -> S [bs,nh,T,Tk]."""
+
+    @staticmethod
+    def forward(ctx, q, k):
+        q, k = q.contiguous(), k.contiguous()
+        bs, T, nh, hd = q.shape
+        Tk, nkv = k.shape[1], k.shape[2]
+        rep = nh // nkv
+        s = torch.empty((bs, nh, T, Tk), dtype=q.dtype, device=q.device)
+        for b in range(bs):
+            gemm(q, k, s, T, Tk, hd, nh * hd, nkv * hd, Tk, True, True, batch_o=nkv, batch_i=rep,
+                 sa=(rep * hd, hd), sb=(hd, 0), sc=(rep * T * Tk, T * Tk),
+                 a_off=b * T * nh * hd, b_off=b * Tk * nkv * hd, c_off=b * nh * T * Tk)
+        ctx.save_for_backward(q, k)
+        return s
+
+    @staticmethod
+    def backward(ctx, gs):
+        q, k = ctx.saved_tensors
+        gs = gs.contiguous()
+        bs, T, nh, hd = q.shape
+        Tk, nkv = k.shape[1], k.shape[2]
+        rep = nh // nkv
+        gq = torch.empty_like(q)
+        gk_full = torch.empty((bs, Tk, nh, hd), dtype=k.dtype, device=k.device)
+        for b in range(bs):
+            # dQ[t,d] = sum_t' dS[t,t'] K[t',d]
+            gemm(gs, k, gq, T, hd, Tk, Tk, nkv * hd, nh * hd, True, False, batch_o=nkv, batch_i=rep,
+                 sa=(rep * T * Tk, T * Tk), sb=(hd, 0), sc=(rep * hd, hd),
+                 a_off=b * nh * T * Tk, b_off=b * Tk * nkv * hd, c_off=b * T * nh * hd)
+            # dK[t',d] = sum_t dS[t,t'] Q[t,d]    (per q-head, reduced over rep below)
+            gemm(gs, q, gk_full, Tk, hd, T, Tk, nh * hd, nh * hd, False, False, batch_o=nh, batch_i=1,
+                 sa=(T * Tk, 0), sb=(hd, 0), sc=(hd, 0),
+                 a_off=b * nh * T * Tk, b_off=b * T * nh * hd, c_off=b * Tk * nh * hd)
+        gk = gk_full if rep == 1 else gk_full.view(bs, Tk, nkv, rep, hd).sum(dim=3)
+        return gq, gk
+
+
+class AttnPVFn(torch.autograd.Function):
+    """O[b,:,h,:] = P[b,h] @ V[b,:,h//rep,:]  (models/int_llama_layer.py:163).  p [bs,nh,T,Tk],
+    v [bs,Tk,nkv,hd] -> o [bs,T,nh,hd]."""
+
+    @staticmethod
+    def forward(ctx, p, v):
+        p, v = p.contiguous(), v.contiguous()
+        bs, nh, T, Tk = p.shape
+        nkv, hd = v.shape[2], v.shape[3]
+        rep = nh // nkv
+        o = torch.empty((bs, T, nh, hd), dtype=p.dtype, device=p.device)
+        for b in range(bs):
+            gemm(p, v, o, T, hd, Tk, Tk, nkv * hd, nh * hd, True, False, batch_o=nkv, batch_i=rep,
+                 sa=(rep * T * Tk, T * Tk), sb=(hd, 0), sc=(rep * hd, hd),
+                 a_off=b * nh * T * Tk, b_off=b * Tk * nkv * hd, c_off=b * T * nh * hd)
+        ctx.save_for_backward(p, v)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        p, v = ctx.saved_tensors
+        go = go.contiguous()
+        bs, nh, T, Tk = p.shape
+        nkv, hd = v.shape[2], v.shape[3]
+        rep = nh // nkv
+        gp = torch.empty_like(p)
+        gv_full = torch.empty((bs, Tk, nh, hd), dtype=v.dtype, device=v.device)
+        for b in range(bs):
+            # dP[t,t'] = sum_d dO[t,d] V[t',d]
+            gemm(go, v, gp, T, Tk, hd, nh * hd, nkv * hd, Tk, True, True, batch_o=nkv, batch_i=rep,
+                 sa=(rep * hd, hd), sb=(hd, 0), sc=(rep * T * Tk, T * Tk),
+                 a_off=b * T * nh * hd, b_off=b * Tk * nkv * hd, c_off=b * nh * T * Tk)
+            # dV[t',d] = sum_t P[t,t'] dO[t,d]
+            gemm(p, go, gv_full, Tk, hd, T, Tk, nh * hd, nh * hd, False, False, batch_o=nh, batch_i=1,
+                 sa=(T * Tk, 0), sb=(hd, 0), sc=(hd, 0),
+                 a_off=b * nh * T * Tk, b_off=b * T * nh * hd, c_off=b * Tk * nh * hd)
+        gv = gv_full if rep == 1 else gv_full.view(bs, Tk, nkv, rep, hd).sum(dim=3)
+        return gp, gv
+
+
+# ------------------------------------------------------------------------------------------------------
+# norms and glue
+# ------------------------------------------------------------------------------------------------------
+class NormFn(torch.autograd.Function):
+    """OmniLlamaRMSNorm / OmniLayerNorm (quantize/omni_norm.py:26-34,52-63)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, is_ln):
+        x = x.contiguous()
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        w32, b32 = _f32(w), _f32(b)
+        y = torch.empty_like(x)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if is_ln else None
+        C.call("oq_norm_fwd", C.ptr(x), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), float(eps), int(is_ln),
+               C.ptr(y), C.fptr(rstd), C.fptr(mean), C.stream())
+        ctx.save_for_backward(x, w32, rstd, mean)
+        ctx.is_ln, ctx.has_b = is_ln, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w32, rstd, mean = ctx.saved_tensors
+        gy = gy.contiguous()
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        gx = torch.empty_like(x)
+        gw = torch.zeros((cols,), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
+        gb = torch.zeros((cols,), dtype=torch.float32, device=x.device) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        C.call("oq_norm_bwd", C.ptr(x), C.ptr(gy), C.dt(x), rows, cols, C.fptr(w32), C.fptr(rstd), C.fptr(mean),
+               int(ctx.is_ln), C.ptr(gx), C.fptr(gw), C.fptr(gb), C.stream())
+        return gx, gw, gb, None, None
+
+
+class RopeFn(torch.autograd.Function):
+    """x [bs,T,heads,hd] rotated with cos/sin [T,hd] (f32, already gathered by position_ids)."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin):
+        x = x.contiguous()
+        bs, T, nh, hd = x.shape
+        y = torch.empty_like(x)
+        for b in range(bs):
+            C.call("oq_rope", x.data_ptr() + b * T * nh * hd * x.element_size(),
+                   y.data_ptr() + b * T * nh * hd * x.element_size(), C.dt(x), T, nh, hd, C.fptr(cos), C.fptr(sin), 0,
+                   C.stream())
+        ctx.save_for_backward(cos, sin)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        cos, sin = ctx.saved_tensors
+        gy = gy.contiguous()
+        bs, T, nh, hd = gy.shape
+        gx = torch.empty_like(gy)
+        for b in range(bs):
+            C.call("oq_rope", gy.data_ptr() + b * T * nh * hd * gy.element_size(),
+                   gx.data_ptr() + b * T * nh * hd * gy.element_size(), C.dt(gy), T, nh, hd, C.fptr(cos), C.fptr(sin), 1,
+                   C.stream())
+        return gx, None, None
+
+
+class SiluMulFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gate, up):
+        gate, up = gate.contiguous(), up.contiguous()
+        y = torch.empty_like(gate)
+        C.call("oq_silu_mul_fwd", C.ptr(gate), C.ptr(up), C.ptr(y), C.dt(gate), gate.numel(), C.stream())
+        ctx.save_for_backward(gate, up)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gate, up = ctx.saved_tensors
+        gy = gy.contiguous()
+        gg, gu = torch.empty_like(gate), torch.empty_like(up)
+        C.call("oq_silu_mul_bwd", C.ptr(gate), C.ptr(up), C.ptr(gy), C.ptr(gg), C.ptr(gu), C.dt(gate), gate.numel(),
+               C.stream())
+        return gg, gu
+
+
+class ReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        C.call("oq_relu_fwd", C.ptr(x), C.ptr(y), C.dt(x), x.numel(), C.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        C.call("oq_relu_bwd", C.ptr(x), C.ptr(gy), C.ptr(gx), C.dt(x), x.numel(), C.stream())
+        return gx
+
+
+class SoftmaxFn(torch.autograd.Function):
+    """p = softmax(max(s*alpha + mask, finfo.min)) in f32 (models/int_llama_layer.py:143-160)."""
+
+    @staticmethod
+    def forward(ctx, s, mask, alpha):
+        s = s.contiguous()
+        cols = s.shape[-1]
+        rows = s.numel() // cols
+        p = torch.empty_like(s)
+        m32, mrows = None, 0
+        if mask is not None:
+            m32 = mask.detach().float().contiguous().view(-1, cols)
+            mrows = m32.shape[0]
+        C.call("oq_softmax_fwd", C.ptr(s), C.ptr(p), C.dt(s), rows, cols, float(alpha), C.fptr(m32), mrows, C.stream())
+        ctx.save_for_backward(p)
+        ctx.alpha = float(alpha)
+        return p
+
+    @staticmethod
+    def backward(ctx, gp):
+        (p,) = ctx.saved_tensors
+        gp = gp.contiguous()
+        cols = p.shape[-1]
+        rows = p.numel() // cols
+        gs = torch.empty_like(p)
+        C.call("oq_softmax_bwd", C.ptr(p), C.ptr(gp), C.ptr(gs), C.dt(p), rows, cols, ctx.alpha, C.stream())
+        return gs, None, None
+
+
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        y = torch.empty_like(a)
+        C.call("oq_add", C.ptr(a), C.ptr(b), C.ptr(y), C.dt(a), a.numel(), C.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, gy
+
+
+class ScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, s):
+        a = a.contiguous()
+        y = torch.empty_like(a)
+        C.call("oq_scale", C.ptr(a), float(s), C.ptr(y), C.dt(a), a.numel(), C.stream())
+        ctx.s = float(s)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        C.call("oq_scale", C.ptr(gy), ctx.s, C.ptr(gx), C.dt(gy), gy.numel(), C.stream())
+        return gx, None
+
+
+class MSELossFn(torch.autograd.Function):
+    """loss = mse(t1, out) (+ mse(t2, out)) as one fused kernel that also writes d loss / d out
+    (quantize/omniquant.py:220-222).  Returns a 0-dim f32 tensor that stays on the device."""
+
+    @staticmethod
+    def forward(ctx, out, t1, t2):
+        out, t1 = out.contiguous(), t1.contiguous()
+        t2 = t2.contiguous() if t2 is not None else None
+        loss = torch.zeros((1,), dtype=torch.float32, device=out.device)
+        g = torch.empty_like(out)
+        C.call("oq_mse_fwd_bwd", C.ptr(out), C.ptr(t1), C.ptr(t2), C.dt(out), out.numel(), 1.0, C.fptr(loss), C.ptr(g),
+               C.stream())
+        ctx.save_for_backward(g)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gl):
+        (g,) = ctx.saved_tensors
+        # d loss is 1.0 in the calibration loop; a different upstream factor is applied with the scale kernel
+        return ScaleByTensor.apply_raw(g, gl), None, None
+
+
+class ScaleByTensor:
+    @staticmethod
+    def apply_raw(g, gl):
+        # gl is a 0-dim tensor; avoid a host sync: multiply on device (plumbing op, 1 launch)
+        return g * gl.to(g.dtype)
+
+
+def cast(x, dtype):
+    """dtype conversion on the HIP path (RNE)."""
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    n = x.numel()
+    if n % 8 != 0:
+        return x.to(dtype)
+    C.call("oq_cast", C.ptr(x), C.dt(x), C.ptr(y), C._DT[dtype], n, C.stream())
+    return y
+
+
+def attention_scale(hd):
+    return 1.0 / math.sqrt(hd)

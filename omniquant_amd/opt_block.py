@@ -1,0 +1,110 @@
+"""Quantised OPT decoder block on the HIP path.  Surface = reference models/int_opt_layer.py.
+
+q (after the 1/sqrt(hd) scaling), k and v are fake-quantised per token over the FULL hidden dim before the
+head split (models/int_opt_layer.py:96-97,124-130), then viewed as [bs, T, heads, hd] for the attention GEMMs.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .block_common import QuantBlockMixin
+from .linear import QuantLinear
+from .matmul import QuantMatMul
+from .norm import OmniLayerNorm
+
+
+class QuantOPTAttention(nn.Module):
+    def __init__(self, org_module: nn.Module, embed_dim: int, num_heads: int, dropout: float = 0.0,
+                 is_decoder: bool = False, bias: bool = True, args=None, disable_act_quant=False):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self.head_dim = embed_dim // num_heads
+        if (self.head_dim * num_heads) != self.embed_dim:
+            raise ValueError(f"embed_dim must be divisible by num_heads (got `embed_dim`: {self.embed_dim}"
+                             f" and `num_heads`: {num_heads}).")
+        self.scaling = self.head_dim ** -0.5
+        self.is_decoder = is_decoder
+        self.k_proj = QuantLinear(org_module.k_proj, args.weight_quant_params, args.act_quant_params)
+        self.v_proj = QuantLinear(org_module.v_proj, args.weight_quant_params, args.act_quant_params)
+        self.q_proj = QuantLinear(org_module.q_proj, args.weight_quant_params, args.act_quant_params)
+        self.out_proj = QuantLinear(org_module.out_proj, args.weight_quant_params, args.act_quant_params)
+        self.qkt_matmul = QuantMatMul(args.q_quant_params, args.k_quant_params, matmul_func=torch.bmm)
+        self.pv_matmul = QuantMatMul(args.p_quant_params, args.v_quant_params, matmul_func=torch.bmm)
+        self.use_weight_quant = False
+        self.use_act_quant = False
+
+    def forward(self, hidden_states, key_value_states=None, past_key_value=None, attention_mask=None,
+                layer_head_mask=None, output_attentions=False):
+        if key_value_states is not None or past_key_value is not None or layer_head_mask is not None or output_attentions:
+            raise NotImplementedError("the calibration hot path runs self-attention without cache / head masks")
+        bsz, tgt_len, _ = hidden_states.size()
+        nh, hd = self.num_heads, self.head_dim
+        q = ops.ScaleFn.apply(self.q_proj(hidden_states), self.scaling)
+        q = self.qkt_matmul.quant_x1(q)
+        k = self.qkt_matmul.quant_x2(self.k_proj(hidden_states))
+        v = self.pv_matmul.quant_x2(self.v_proj(hidden_states))
+        q, k, v = (t.view(bsz, tgt_len, nh, hd) for t in (q, k, v))
+        scores = self.qkt_matmul.scores(q, k)
+        mask = None
+        if attention_mask is not None:
+            if attention_mask.size() != (bsz, 1, tgt_len, tgt_len):
+                raise ValueError(f"Attention mask should be of size {(bsz, 1, tgt_len, tgt_len)}, but is "
+                                 f"{attention_mask.size()}")
+            mask = attention_mask[0, 0]
+        probs = ops.SoftmaxFn.apply(scores, mask, 1.0)
+        probs = self.pv_matmul.quant_x1(probs)
+        attn = self.pv_matmul.apply_probs(probs, v).view(bsz, tgt_len, self.embed_dim)
+        return self.out_proj(attn), None, None
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant = weight_quant
+        self.use_act_quant = act_quant
+        for m in self.modules():
+            if isinstance(m, (QuantLinear, QuantMatMul)):
+                m.set_quant_state(weight_quant, act_quant)
+
+
+class QuantOPTDecoderLayer(QuantBlockMixin, nn.Module):
+    def __init__(self, config, ori_layer, args):
+        super().__init__()
+        self.embed_dim = config.hidden_size
+        self.self_attn = QuantOPTAttention(org_module=ori_layer.self_attn, embed_dim=self.embed_dim,
+                                           num_heads=config.num_attention_heads, dropout=config.attention_dropout,
+                                           is_decoder=True, bias=config.enable_bias, args=args)
+        self.do_layer_norm_before = config.do_layer_norm_before
+        self.dropout = config.dropout
+        self.self_attn_layer_norm = OmniLayerNorm(ori_layer.self_attn_layer_norm)
+        self.fc1 = QuantLinear(ori_layer.fc1, weight_quant_params=args.weight_quant_params,
+                               act_quant_params=args.act_quant_params)
+        self.fc2 = QuantLinear(ori_layer.fc2, weight_quant_params=args.weight_quant_params,
+                               act_quant_params=args.act_quant_params)
+        self.final_layer_norm = OmniLayerNorm(ori_layer.final_layer_norm)
+        self.type = ori_layer.fc1.weight.dtype
+
+    def _let_names(self):
+        a = self.self_attn
+        return dict(q=a.q_proj, k=a.k_proj, v=a.v_proj, o=a.out_proj, fc1=[self.fc1], last=self.fc2,
+                    ln1=self.self_attn_layer_norm, ln2=self.final_layer_norm)
+
+    def forward(self, hidden_states, attention_mask=None, layer_head_mask=None, output_attentions=False,
+                use_cache=False, past_key_value=None, **kwargs) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        if use_cache or output_attentions:
+            raise NotImplementedError("the calibration hot path runs without KV cache / attention outputs")
+        residual = hidden_states
+        h = self.self_attn_layer_norm(hidden_states) if self.do_layer_norm_before else hidden_states
+        h, _, _ = self.self_attn(hidden_states=h, past_key_value=past_key_value, attention_mask=attention_mask,
+                                 layer_head_mask=layer_head_mask, output_attentions=output_attentions)
+        hidden_states = ops.AddFn.apply(residual, h)
+        if not self.do_layer_norm_before:
+            hidden_states = self.self_attn_layer_norm(hidden_states)
+        residual = hidden_states
+        h = self.final_layer_norm(hidden_states) if self.do_layer_norm_before else hidden_states
+        h = self.fc2(ops.ReluFn.apply(self.fc1(h)))
+        hidden_states = ops.AddFn.apply(residual, h)
+        if not self.do_layer_norm_before:
+            hidden_states = self.final_layer_norm(hidden_states)
+        return (hidden_states,)

@@ -1,0 +1,82 @@
+"""-m gpu parity tests of the block-level hot path: one sample-step and whole calibration trajectories on the
+HIP path vs the golden vectors generated from the reference (float32 parity mode), plus bf16-mode sanity and the
+hipGraph-replayed step."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from gpu_helpers import T, build_block, make_args, make_cfg, rel_err, run_block_step_parity
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+STEP_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g3_step_*.npz")))
+TRAJ_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g4_traj_*.npz")))
+
+
+@pytest.mark.parametrize("fname", STEP_FILES)
+def test_block_step_f32(fname):
+    e = run_block_step_parity(fname, torch.float32, DEV)
+    assert e["tmp"] < 1e-5, e          # LET temporaries + fake-quant weights
+    assert e["out"] < 2e-3, e          # a handful of activation rounding ties may flip (1 level of 16)
+    assert e["loss"] < 1e-3, e
+    assert e["grad"] < 3e-2, e["per_grad"]
+
+
+@pytest.mark.parametrize("fname", ["g3_step_llama_w4a4_lwc_let.npz", "g3_step_opt_w4a4_lwc_let.npz"])
+def test_block_step_bf16_sanity(fname):
+    """bf16 MFMA mode: same graph, looser numerics (8-bit mantissa operands)."""
+    e = run_block_step_parity(fname, torch.bfloat16, DEV)
+    assert e["tmp"] < 1e-2 and e["out"] < 0.15 and e["loss"] < 0.1, e
+
+
+def _run_traj(fname, use_graph, dtype=torch.float32):
+    from omniquant_amd.calibrate import calibrate_layers
+    from omniquant_amd.synthetic import make_layer
+    g, m = load_golden(fname)
+    cfg, args = make_cfg(m), make_args(m)
+    layers = []
+    for i in range(m["n_layers"]):
+        w = {k[len(f"w{i}."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(f"w{i}.")}
+        layers.append(make_layer(cfg, weights=w, device=DEV))
+    sc = {k[len("act_scales."):]: T(v) for k, v in g.items() if k.startswith("act_scales.")}
+    sh = {k[len("act_shifts."):]: T(v) for k, v in g.items() if k.startswith("act_shifts.")}
+    pos = torch.from_numpy(g["position_ids"]).to(DEV)
+    qlayers, omni, losses, (qi, fi) = calibrate_layers(layers, cfg, args, T(g["inps"], DEV), T(g["mask"], DEV), pos, sc, sh,
+                                                       use_graph=use_graph, compute_dtype=dtype)
+    return g, m, omni, losses, qi, fi
+
+
+@pytest.mark.parametrize("fname", TRAJ_FILES)
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_trajectory_f32(fname, use_graph):
+    """2 layers x 4 samples x 2 epochs of AdamW on the HIP path; learned clip/scale/shift tensors must match the
+    reference within 1e-3 (north-star tolerance, relative to each tensor's magnitude)."""
+    g, m, omni, losses, qi, fi = _run_traj(fname, use_graph)
+    ref_losses = g["losses"]
+    assert len(losses) == len(ref_losses)
+    np.testing.assert_allclose(np.asarray(losses), ref_losses, rtol=2e-2)
+    for i in range(m["n_layers"]):
+        keys = [k for k in g if k.startswith(f"omni.{i}.")]
+        assert {k[len(f"omni.{i}."):] for k in keys} == set(omni[i].keys())
+        for k in keys:
+            n = k[len(f"omni.{i}."):]
+            assert omni[i][n].dtype == torch.float16 and tuple(omni[i][n].shape) == g[k].shape
+            ref = g[k].astype(np.float64)
+            got = omni[i][n].double().numpy()
+            tol = 1e-3 * max(np.abs(ref).max(), 1e-6) + 1e-3     # fp16 storage: one ulp at |4| is 3.9e-3/2
+            assert np.abs(got - ref).max() <= tol, f"layer {i} {n}: {np.abs(got - ref).max()} > {tol}"
+        assert rel_err(fi.float(), g[f"fp_out.{m['n_layers'] - 1}"]) < 1e-3 if i == m["n_layers"] - 1 else True
+    assert rel_err(qi.float(), g[f"quant_out.{m['n_layers'] - 1}"]) < 5e-2
+
+
+def test_trajectory_bf16_loss_curve():
+    """bf16 production mode follows the reference loss curve (not elementwise-identical by construction)."""
+    g, m, omni, losses, qi, fi = _run_traj("g4_traj_llama_w4a4_lwc_let.npz", True, torch.bfloat16)
+    ref = g["losses"]
+    assert np.isfinite(losses).all()
+    assert abs(np.mean(losses) - ref.mean()) / ref.mean() < 0.1

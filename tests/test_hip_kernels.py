@@ -1,0 +1,354 @@
+"""-m gpu parity tests of the individual HIP kernels, called through the C ABI (ctypes), against
+(a) the golden vectors generated from the reference and (b) plain torch float64/float32 restatements."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a, dtype=torch.float32):
+    return torch.from_numpy(np.asarray(a)).to(dtype).to(DEV)
+
+
+def assert_close(got, ref, rtol, atol, what="", max_bad_frac=0.0):
+    got = got.detach().double().cpu().numpy()
+    ref = np.asarray(ref, np.float64).reshape(got.shape)
+    nan_g, nan_r = np.isnan(got), np.isnan(ref)
+    assert (nan_g == nan_r).all(), f"{what}: NaN pattern differs"
+    bad = np.abs(got - ref)[~nan_r] > (atol + rtol * np.abs(ref[~nan_r]))
+    frac = bad.mean() if bad.size else 0.0
+    assert frac <= max_bad_frac, f"{what}: {bad.sum()} / {bad.size} out of tolerance (max abs err " \
+                                 f"{np.abs(got - ref)[~nan_r].max():.3e})"
+
+
+G1, G1META = load_golden("g1_quantizer.npz")
+
+
+@pytest.mark.parametrize("i", range(len(G1META["cases"])))
+def test_fakequant_vs_reference_golden(i):
+    """UniformAffineQuantizer fwd + bwd on the HIP path vs vectors produced by the reference's own class."""
+    from omniquant_amd import UniformAffineQuantizer, OQError
+    c = G1META["cases"][i]
+    shape = c["shape"]
+    q = UniformAffineQuantizer(n_bits=c["n_bits"], symmetric=c["symmetric"], per_channel_axes=[0],
+                               dynamic_method=c["dynamic_method"], group_size=c["group_size"],
+                               shape=tuple(shape) if c["lwc"] else None, lwc=c["lwc"]).to(DEV)
+    if c["lwc"]:
+        with torch.no_grad():
+            q.upbound_factor.copy_(T(G1[f"c{i}_up"]))
+            q.lowbound_factor.copy_(T(G1[f"c{i}_low"]))
+    need_gx = f"c{i}_gx" in G1
+    x = T(G1[f"c{i}_x"]).requires_grad_(need_gx)
+    if c["deficiency"] > 0:
+        with pytest.raises((NotImplementedError, OQError)):
+            q(x)
+        return
+    y = q(x)
+    # scale may differ by an ulp (sigmoid/exp implementation), which can flip a rounding tie for a few elements:
+    # allow <=0.2 % of elements to be off by one quantisation step, everything else tight.
+    step = float(np.nanmax(G1[f"c{i}_scale"])) if not np.isnan(G1[f"c{i}_scale"]).all() else 1.0
+    assert_close(q.scale, G1[f"c{i}_scale"], 2e-6, 1e-9, c["tag"] + " scale")
+    assert_close(q.round_zero_point, G1[f"c{i}_zp"], 0, 0, c["tag"] + " zp", max_bad_frac=0.002)
+    assert_close(y, G1[f"c{i}_y"], 1e-5, 1e-7, c["tag"] + " y", max_bad_frac=0.002)
+    assert_close(y, G1[f"c{i}_y"], 0, 1.001 * step, c["tag"] + " y (one step)")
+    if y.requires_grad:
+        (y * T(G1[f"c{i}_G"])).sum().backward()
+        big = c["tag"] == "a4_tok_positive"
+        if need_gx:
+            assert_close(x.grad, G1[f"c{i}_gx"], 1e-4, 5e-4 if big else 2e-5, c["tag"] + " gx", max_bad_frac=0.002)
+        if c["lwc"]:
+            sc = max(np.abs(G1[f"c{i}_gup"]).max(), np.abs(G1[f"c{i}_glow"]).max(), 1e-6)
+            assert_close(q.upbound_factor.grad, G1[f"c{i}_gup"], 1e-3, 2e-4 * sc, c["tag"] + " gup", max_bad_frac=0.01)
+            assert_close(q.lowbound_factor.grad, G1[f"c{i}_glow"], 1e-3, 2e-4 * sc, c["tag"] + " glow", max_bad_frac=0.01)
+
+
+@pytest.mark.parametrize("in_dtype,out_dtype", [(torch.float16, torch.bfloat16), (torch.float16, torch.float32),
+                                                (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("rows,cols,group", [(64, 4096, None), (32, 11008, None), (48, 4096, 128), (16, 1024, 64),
+                                             (8, 28672, None), (8, 8192, 64)])
+def test_fakequant_let_fused_vs_oracle(in_dtype, out_dtype, rows, cols, group):
+    """Fused LET transform + LWC fake quant + W@shift (fwd and every gradient) at production row lengths."""
+    from oracle import ref_cpu as R
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    W = (torch.randn(rows, cols, generator=g) * 0.02).to(in_dtype)
+    cm = (torch.rand(cols, generator=g) + 0.5)
+    rd = (torch.rand(rows, generator=g) + 0.5)
+    rm = (torch.rand(rows, generator=g) + 0.5)
+    sh = torch.randn(cols, generator=g) * 0.1
+    nseg = rows * (cols // (group or cols))
+    up = 4 + torch.randn(nseg, 1, generator=g)
+    low = 4 + torch.randn(nseg, 1, generator=g)
+    G = torch.randn(rows, cols, generator=g)
+    Gs = torch.randn(rows, generator=g)
+    # oracle (fp32 CPU)
+    leaves = [t.clone().requires_grad_(True) for t in (cm, rd, rm, sh, up, low)]
+    ocm, ord_, orm, osh, oup, olow = leaves
+    Wf = W.float()
+    xo = ((Wf * ocm.view(1, -1)) / ord_.view(-1, 1)) * orm.view(-1, 1)
+    yo = R.fake_quant(xo, 4, group, oup, olow)
+    wso = Wf @ osh
+    ((yo * G).sum() + (wso * Gs).sum()).backward()
+    # HIP
+    dl = [t.clone().to(DEV).requires_grad_(True) for t in (cm, rd, rm, sh, up, low)]
+    dcm, drd, drm, dsh, dup, dlow = dl
+    y, ws = ops.fake_quant(W.to(DEV), 4, group, dup, dlow, False, out_dtype, None, dcm, drd, drm, dsh)
+    assert y.dtype == out_dtype
+    tol = 1e-5 if out_dtype == torch.float32 else 8e-3
+    step = float(yo.detach().abs().max()) / 7
+    assert_close(y.float(), yo.detach().numpy(), tol, tol * 1e-2, "y", max_bad_frac=0.002)
+    assert_close(y.float(), yo.detach().numpy(), 0, 1.01 * step + 1e-2 * step, "y one-step")
+    assert_close(ws, wso.detach().numpy(), 1e-4, 1e-5, "wshift")
+    ((y.float() * G.to(DEV)).sum() + (ws * Gs.to(DEV)).sum()).backward()
+    for name, a, b in zip(("col_mul", "row_div", "row_mul", "shift", "up", "low"), dl, leaves):
+        ref = b.grad.numpy()
+        sc = max(np.abs(ref).max(), 1e-9)
+        assert_close(a.grad / sc, ref / sc, 5e-3, 2e-3, "grad " + name, max_bad_frac=0.01)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 192), (16, 64, 64), (200, 136, 72), (2048, 512, 1024)])
+def test_gemm_layouts(dtype, a_kc, b_kc, M, N, K):
+    """C = A(m,k) B(n,k) for every operand layout, ragged tiles included; asymmetric integer-valued data makes a
+    transposed or permuted fragment show up as an O(1) error."""
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    A = torch.randint(-3, 4, (M, K), generator=g).float() + 0.25 * torch.arange(K).remainder(3)[None, :]
+    B = torch.randint(-3, 4, (N, K), generator=g).float() - 0.5 * torch.arange(N).remainder(2)[:, None]
+    ref = (A.double() @ B.double().T)
+    a = (A if a_kc else A.T.contiguous()).to(dtype).to(DEV)
+    b = (B if b_kc else B.T.contiguous()).to(dtype).to(DEV)
+    bias = torch.randn(N, generator=g)
+    for out_dtype in (torch.float32, dtype):
+        c = torch.full((M, N), float("nan"), dtype=out_dtype, device=DEV)
+        ops.gemm(a, b, c, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc, b_kc, bias=bias.to(DEV), alpha=0.5)
+        want = 0.5 * ref + bias.double()[None, :]
+        tol = 1e-5 if out_dtype == torch.float32 else 1e-2
+        assert_close(c.float(), want.numpy(), tol, tol, f"gemm {dtype} akc={a_kc} bkc={b_kc} out={out_dtype}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nh,nkv", [(4, 4), (8, 2)])
+def test_attention_gemms(dtype, nh, nkv):
+    """AttnScoresFn / AttnPVFn (strided-batched, GQA via zero stride) fwd + bwd vs torch."""
+    from omniquant_amd import ops
+    bs, Tn, hd = 2, 128, 64
+    g = torch.Generator().manual_seed(nh)
+    q = torch.randn(bs, Tn, nh, hd, generator=g)
+    k = torch.randn(bs, Tn, nkv, hd, generator=g)
+    v = torch.randn(bs, Tn, nkv, hd, generator=g)
+    rep = nh // nkv
+    ql, kl, vl = (t.clone().to(dtype).float().requires_grad_(True) for t in (q, k, v))
+    kr = kl.repeat_interleave(rep, dim=2)
+    vr = vl.repeat_interleave(rep, dim=2)
+    s_ref = torch.einsum("bthd,bshd->bhts", ql, kr)
+    p_ref = torch.softmax(s_ref / math.sqrt(hd), dim=-1)
+    o_ref = torch.einsum("bhts,bshd->bthd", p_ref.to(dtype).float(), vr)
+    Go = torch.randn(o_ref.shape, generator=g)
+    (o_ref * Go).sum().backward()
+    qd, kd, vd = (t.clone().to(dtype).to(DEV).requires_grad_(True) for t in (q, k, v))
+    s = ops.AttnScoresFn.apply(qd, kd)
+    p = ops.SoftmaxFn.apply(s, None, 1.0 / math.sqrt(hd))
+    o = ops.AttnPVFn.apply(p, vd)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert_close(s.float(), s_ref.detach().numpy(), tol, tol, "scores")
+    assert_close(o.float(), o_ref.detach().numpy(), tol, tol, "out")
+    (o.float() * Go.to(DEV)).sum().backward()
+    for n, a, b in (("gq", qd, ql), ("gk", kd, kl), ("gv", vd, vl)):
+        sc = float(b.grad.abs().max())
+        assert_close(a.grad.float() / sc, (b.grad / sc).numpy(), tol, tol, n)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("is_ln", [False, True])
+@pytest.mark.parametrize("rows,cols", [(37, 64), (128, 4096), (16, 8192)])
+def test_norm(dtype, is_ln, rows, cols):
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(cols)
+    x = torch.randn(rows, cols, generator=g).to(dtype)
+    w = 1 + 0.1 * torch.randn(cols, generator=g)
+    b = 0.1 * torch.randn(cols, generator=g)
+    G = torch.randn(rows, cols, generator=g)
+    xl, wl, bl = x.float().clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    if is_ln:
+        yr = torch.nn.functional.layer_norm(xl, (cols,), wl, bl, 1e-5)
+    else:
+        yr = wl * (xl * torch.rsqrt(xl.pow(2).mean(-1, keepdim=True) + 1e-6)) + bl
+    (yr * G).sum().backward()
+    xd, wd, bd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.NormFn.apply(xd, wd, bd, 1e-5 if is_ln else 1e-6, is_ln)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert_close(y.float(), yr.detach().numpy(), tol, tol, "y")
+    (y.float() * G.to(DEV)).sum().backward()
+    assert_close(xd.grad.float(), xl.grad.numpy(), max(tol, 1e-4), max(tol, 1e-4), "gx")
+    sc = float(wl.grad.abs().max())
+    assert_close(wd.grad / sc, (wl.grad / sc).numpy(), 1e-3, 1e-3 if dtype == torch.float32 else 2e-2, "gw")
+    assert_close(bd.grad, bl.grad.numpy(), 1e-3, 1e-3 if dtype == torch.float32 else 2e-2, "gb")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rope_silu_relu_softmax_mse(dtype):
+    from omniquant_amd import ops, _capi as C
+    g = torch.Generator().manual_seed(0)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    # rope
+    bs, Tn, nh, hd = 2, 16, 4, 32
+    x = torch.randn(bs, Tn, nh, hd, generator=g).to(dtype)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(Tn).float(), inv)
+    emb = torch.cat((fr, fr), -1)
+    cos, sin = emb.cos(), emb.sin()
+    xl = x.float().clone().requires_grad_(True)
+    rot = torch.cat((-xl[..., hd // 2:], xl[..., :hd // 2]), -1)
+    yr = xl * cos[None, :, None, :] + rot * sin[None, :, None, :]
+    G = torch.randn(yr.shape, generator=g)
+    (yr * G).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.RopeFn.apply(xd, cos.to(DEV).contiguous(), sin.to(DEV).contiguous())
+    assert_close(y.float(), yr.detach().numpy(), tol, tol, "rope")
+    (y.float() * G.to(DEV)).sum().backward()
+    assert_close(xd.grad.float(), xl.grad.numpy(), tol, tol, "rope grad")
+    # silu*mul, relu
+    a, b = torch.randn(64, 256, generator=g).to(dtype), torch.randn(64, 256, generator=g).to(dtype)
+    al, bl = a.float().clone().requires_grad_(True), b.float().clone().requires_grad_(True)
+    yr = torch.nn.functional.silu(al) * bl
+    G = torch.randn(64, 256, generator=g)
+    (yr * G).sum().backward()
+    ad, bd = a.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.SiluMulFn.apply(ad, bd)
+    assert_close(y.float(), yr.detach().numpy(), tol, tol, "silu_mul")
+    (y.float() * G.to(DEV)).sum().backward()
+    assert_close(ad.grad.float(), al.grad.numpy(), tol, tol, "silu ggate")
+    assert_close(bd.grad.float(), bl.grad.numpy(), tol, tol, "silu gup")
+    ad2 = a.to(DEV).requires_grad_(True)
+    y = ops.ReluFn.apply(ad2)
+    (y.float() * G.to(DEV)).sum().backward()
+    assert_close(y.float(), torch.relu(a.float()).numpy(), 0, 0, "relu")
+    assert_close(ad2.grad.float(), (G * (a.float() > 0)).to(dtype).float().numpy(), tol, tol, "relu grad")
+    # masked softmax (causal, finfo.min mask, clamp)
+    rows, cols = 4 * 48, 48
+    s = (torch.randn(rows, cols, generator=g) * 4).to(dtype)
+    mask = torch.triu(torch.full((48, 48), torch.finfo(torch.float32).min), 1)
+    sl = s.float().clone().requires_grad_(True)
+    z = torch.max(sl.view(4, 48, 48) * 0.3 + mask, torch.tensor(torch.finfo(torch.float32).min))
+    pr = torch.softmax(z, -1).view(rows, cols)
+    G = torch.randn(rows, cols, generator=g)
+    (pr.to(dtype).float() * G).sum().backward()
+    sd = s.to(DEV).requires_grad_(True)
+    p = ops.SoftmaxFn.apply(sd, mask.to(DEV), 0.3)
+    assert_close(p.float(), pr.detach().numpy(), tol, tol, "softmax")
+    (p.float() * G.to(DEV)).sum().backward()
+    assert_close(sd.grad.float(), sl.grad.numpy(), 3 * tol, 3 * tol, "softmax grad")
+    # fused mse + grad
+    out, t1, t2 = (torch.randn(8, 64, generator=g).to(dtype) for _ in range(3))
+    loss = torch.zeros(1, device=DEV)
+    gg = torch.empty(8, 64, dtype=dtype, device=DEV)
+    o_d, t1_d, t2_d = out.to(DEV), t1.to(DEV), t2.to(DEV)
+    C.call("oq_mse_fwd_bwd", C.ptr(o_d), C.ptr(t1_d), C.ptr(t2_d), C.dt(o_d), out.numel(), 1.0, C.fptr(loss), C.ptr(gg), C.stream())
+    ol = out.float().clone().requires_grad_(True)
+    lr = torch.nn.functional.mse_loss(t1.float(), ol) + torch.nn.functional.mse_loss(t2.float(), ol)
+    lr.backward()
+    assert abs(float(loss) - float(lr)) <= 1e-5 * abs(float(lr)) + 1e-7
+    assert_close(gg.float(), ol.grad.numpy(), tol, tol * 1e-2, "mse grad")
+
+
+def test_adamw_gradnorm_truncate_vs_torch():
+    from omniquant_amd import _capi as C
+    g = torch.Generator().manual_seed(1)
+    n, n_let = 5000, 1200
+    p0 = torch.randn(n, generator=g)
+    pt_let = p0[:n_let].clone().requires_grad_(True)
+    pt_lwc = p0[n_let:].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{"params": [pt_let], "lr": 5e-3}, {"params": [pt_lwc], "lr": 1e-2}], weight_decay=0.0)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step, norm, ws = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV), torch.zeros(512, device=DEV)
+    for it in range(5):
+        gr = torch.randn(n, generator=g) * (10.0 ** (it - 2))
+        pt_let.grad, pt_lwc.grad = gr[:n_let].clone(), gr[n_let:].clone()
+        opt.step()
+        gd = gr.to(DEV)
+        C.call("oq_gradnorm", C.fptr(gd), n, C.fptr(norm), C.fptr(ws), C.stream())
+        C.call("oq_adamw", C.fptr(p), C.fptr(gd), C.fptr(m), C.fptr(v), n, n_let, 5e-3, 1e-2, 0.9, 0.999, 1e-8, 0.0,
+               C.fptr(step), C.fptr(norm), C.stream())
+        assert abs(float(norm[0]) - float(gr.norm())) <= 1e-5 * float(gr.norm())
+        assert float(norm[1]) == 1.0
+    want = torch.cat([pt_let.detach(), pt_lwc.detach()])
+    assert_close(p, want.numpy(), 1e-5, 1e-6, "adamw params")
+    assert float(step) == 5.0
+    # non-finite gradient: the step is skipped on the device
+    gd = torch.randn(n, generator=g).to(DEV)
+    gd[17] = float("inf")
+    before = p.clone()
+    C.call("oq_gradnorm", C.fptr(gd), n, C.fptr(norm), C.fptr(ws), C.stream())
+    C.call("oq_adamw", C.fptr(p), C.fptr(gd), C.fptr(m), C.fptr(v), n, n_let, 5e-3, 1e-2, 0.9, 0.999, 1e-8, 0.0,
+           C.fptr(step), C.fptr(norm), C.stream())
+    assert float(norm[1]) == 0.0 and torch.equal(p, before) and float(step) == 5.0
+    # truncate_number vs golden
+    g5, _ = load_golden("g5_misc.npz")
+    x = T(g5["trunc_x"]).contiguous()
+    C.call("oq_truncate", C.fptr(x), x.numel(), 1e-2, C.stream())
+    assert_close(x, g5["trunc_y"], 0, 0, "truncate")
+
+
+def test_bad_arguments_raise():
+    """Error convention of the boundary: negative rc -> OQError with the library's message; CPU tensors refused."""
+    from omniquant_amd import ops, OQError, _capi as C
+    x = torch.randn(4, 20, device=DEV)          # 20 % 8 != 0
+    with pytest.raises(OQError):
+        ops.fake_quant(x, 4)
+    with pytest.raises(OQError):
+        ops.fake_quant(torch.randn(4, 64), 4)   # CPU tensor
+    with pytest.raises(OQError):
+        ops.fake_quant(torch.randn(4, 64, device=DEV), 1)
+    a = torch.randn(16, 12, device=DEV, dtype=torch.bfloat16)   # K=12 not a multiple of 8
+    with pytest.raises(OQError):
+        ops.gemm(a, a, torch.empty(16, 16, device=DEV), 16, 16, 12, 12, 12, 16, True, True)
+
+
+def test_full_size_properties():
+    """LLaMA-7B row shapes (BASELINE configs 1/2), size-independent checks: quantisation grid properties of the
+    fake-quant kernel and a checksum-of-checksums for the bf16 MFMA GEMM in all three layouts."""
+    from omniquant_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(0)
+    W = (torch.randn(4096, 11008, device=DEV, generator=g) * 0.02).half()
+    stash = {}
+    for bits, group in ((4, None), (3, 128)):
+        nseg = 4096 * (11008 // (group or 11008))
+        up = torch.full((nseg, 1), 4.0, device=DEV)
+        y = ops.fake_quant(W, bits, group, up, up.clone(), False, torch.float32, stash)
+        s = stash["scale"].view(4096, -1)
+        seg = group or 11008
+        yv, xv = y.view(4096, -1, seg), W.float().view(4096, -1, seg)
+        lev = torch.round(yv / s[..., None] + stash["zp"].view(4096, -1)[..., None])
+        assert lev.min() >= 0 and lev.max() <= 2 ** bits - 1                     # on the grid
+        hi = torch.sigmoid(torch.tensor(4.0)) * xv.amax(-1, keepdim=True)
+        lo = torch.sigmoid(torch.tensor(4.0)) * xv.amin(-1, keepdim=True)
+        inside = (xv <= hi) & (xv >= lo)
+        err = (yv - xv).abs()
+        assert (err[inside] <= 0.5001 * s[..., None].expand_as(err)[inside] + 1e-7).all()   # half-step bound
+        y2 = ops.fake_quant(W, bits, group, up, up.clone(), False, torch.float32, None)
+        assert torch.equal(y, y2)                                                  # deterministic
+    Tn, K, N = 2048, 4096, 11008
+    X = torch.randn(Tn, K, device=DEV, generator=g).bfloat16()
+    Wb = (torch.randn(N, K, device=DEV, generator=g) * 0.02).bfloat16()
+    Y = torch.empty(Tn, N, device=DEV, dtype=torch.float32)
+    ops.gemm(X, Wb, Y, Tn, N, K, K, K, N, True, True)
+    chk = X.float() @ Wb.float().sum(0)                # sum_n Y[t,n] = X[t,:] . sum_n W[n,:]
+    assert torch.allclose(Y.sum(1), chk, rtol=2e-3, atol=2e-2 * float(chk.abs().max()))
+    dY = torch.randn(Tn, N, device=DEV, generator=g).bfloat16()
+    dX = torch.empty(Tn, K, device=DEV, dtype=torch.float32)
+    ops.gemm(dY, Wb, dX, Tn, K, N, N, K, K, True, False)
+    chk = dY.float() @ Wb.float().sum(1)
+    assert torch.allclose(dX.sum(1), chk, rtol=2e-3, atol=2e-2 * float(chk.abs().max()))
+    dW = torch.empty(N, K, device=DEV, dtype=torch.float32)
+    ops.gemm(dY, X, dW, N, K, Tn, N, K, K, False, False)
+    chk = dY.float().T @ X.float().sum(1)
+    assert torch.allclose(dW.sum(1), chk, rtol=2e-3, atol=2e-2 * float(chk.abs().max()))
