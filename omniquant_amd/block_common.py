@@ -66,7 +66,8 @@ class QuantBlockMixin:
                 mod.use_temporary_parameter = True
 
     def clear_temp_variable(self):
-        for mod in self._quant_linears():
+        nm = self._let_names()
+        for mod in self._quant_linears() + [nm["ln1"], nm["ln2"]]:
             if hasattr(mod, "temp_weight"):
                 del mod.temp_weight
             if hasattr(mod, "temp_bias"):

@@ -128,6 +128,9 @@ class StepRunner:
         self.opt.step()
 
     def _capture(self):
+        """Warm up and capture on the SAME side stream: autograd binds each parameter's AccumulateGrad node to the
+        stream of its first backward; if the capture ran on another stream the `grad +=` kernels would be forked
+        onto the warm-up stream and race with the allocator's reuse of the incoming gradient buffers."""
         opt = self.opt
         snap = [t.clone() for t in (opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count)]
         s = torch.cuda.Stream()
@@ -135,11 +138,12 @@ class StepRunner:
         with torch.cuda.stream(s):
             for _ in range(2):          # warm-up: allocator + lazily cached tables
                 self._step()
+            for t, c in zip((opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count), snap):
+                t.copy_(c)
+            self.qlayer.clear_temp_variable()     # drop the warm-up autograd graph
         torch.cuda.current_stream().wait_stream(s)
-        for t, c in zip((opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count), snap):
-            t.copy_(c)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=s):
             self._step()
 
     def run(self, x, t1, t2=None):

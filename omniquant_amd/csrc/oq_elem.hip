@@ -223,6 +223,10 @@ __global__ void cast_kernel(const TS* x, TD* y, int64_t n) {
     }
 }
 
+__global__ void zero_f32_kernel(float* p, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 // column sums: block handles 64 columns x a slab of rows; lanes along columns (coalesced), then atomics
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_kernel(const T* x, int64_t rows, int64_t cols, float* out) {
@@ -358,7 +362,9 @@ extern "C" int oq_cast(const void* x, int src_dtype, void* y, int dst_dtype, int
 extern "C" int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, float* out, void* stream) {
     OQ_CHECK_ARG(x && out && rows > 0 && cols > 0, "oq_colsum: bad args");
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(out, 0, cols * sizeof(float), st) != hipSuccess) { oq_set_error("oq_colsum: memset failed"); return OQ_E_LAUNCH; }
+    // zeroed with a kernel, not hipMemsetAsync: a memset issued from inside the library was observed NOT to be
+    // re-executed when the enclosing stream capture is replayed as a hipGraph (stale sums on the 2nd replay)
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, out, cols);
     int64_t gy = rows / 64; gy = gy < 1 ? 1 : (gy > 64 ? 64 : gy);
     const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)gy);
     DT_SWITCH("oq_colsum", dtype,

