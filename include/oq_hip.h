@@ -54,8 +54,9 @@ int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int
 /* Backward of the above (closed form of the autograd graph the reference builds).
  *   g [rows,cols] (g_dtype) = dL/dy ; g_wshift [rows] = dL/d wshift (optional)
  * Outputs (each optional, f32): g_up, g_low [rows*cols/seg]; gx [rows,cols] (gx_dtype; only when w itself
- * needs a gradient, i.e. activation quantizers); g_col_mul [cols], g_shift [cols] (ACCUMULATED with float
- * atomics: caller zeroes them); g_row_div, g_row_mul [rows].
+ * needs a gradient, i.e. activation quantizers); g_col_mul [cols], g_shift [cols]; g_row_div, g_row_mul [rows].
+ * The column sums (g_col_mul, g_shift) are reduced deterministically through `workspace` (f32, at least
+ * oq_fakequant_bwd_workspace(rows, cols) floats; only needed when one of the two is requested).
  */
 int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits, int symmetric,
                      const float* col_mul, const float* row_div, const float* row_mul, const float* shift,
@@ -63,7 +64,8 @@ int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int
                      const void* g, int g_dtype, const float* g_wshift,
                      float* g_up, float* g_low, void* gx, int gx_dtype,
                      float* g_col_mul, float* g_shift, float* g_row_div, float* g_row_mul,
-                     void* stream);
+                     float* workspace, int64_t workspace_floats, void* stream);
+int64_t oq_fakequant_bwd_workspace(int64_t rows, int64_t cols);
 
 /* ---- QuantLinear / QuantMatMul GEMM (quantize/int_linear.py:62 F.linear; quantize/int_matmul.py:41-43
  * torch.matmul / torch.bmm, and their autograd: dgrad + wgrad) -------------------------------------------
@@ -86,12 +88,15 @@ int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, float* out, 
 
 /* ---- OmniLlamaRMSNorm / OmniLayerNorm (quantize/omni_norm.py:26-34, :52-63) -----------------------------
  * rms:  y = w * x * rsqrt(mean(x^2)+eps) (+ b);   layer: y = w * (x-mean)/sqrt(var+eps) + b.   w,b f32.
- * bwd: gx [rows,cols]; gw, gb [cols] f32 ACCUMULATED with atomics (caller zeroes). b / gb may be NULL.
+ * bwd: gx [rows,cols]; gw, gb [cols] f32 (gb may be NULL), reduced deterministically through `workspace`
+ * (f32, at least oq_norm_bwd_workspace(rows, cols) floats).
  */
 int oq_norm_fwd(const void* x, int dtype, int64_t rows, int64_t cols, const float* w, const float* b, float eps,
                 int is_layernorm, void* y, float* rstd, float* mean, void* stream);
 int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t rows, int64_t cols, const float* w,
-                const float* rstd, const float* mean, int is_layernorm, void* gx, float* gw, float* gb, void* stream);
+                const float* rstd, const float* mean, int is_layernorm, void* gx, float* gw, float* gb,
+                float* workspace, int64_t workspace_floats, void* stream);
+int64_t oq_norm_bwd_workspace(int64_t rows, int64_t cols);
 
 /* ---- block glue (models/int_llama_layer.py:124-125 RoPE, :44-45 SiLU*up, :153-163 mask+softmax;
  *      models/int_opt_layer.py:151-170; quantize/omniquant.py:220-222 MSE) ---------------------------------

@@ -21,12 +21,12 @@ SIGNATURES = {
     "oq_fakequant_fwd": [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                          _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "oq_fakequant_bwd": [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
-                         _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+                         _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_gemm": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp],
     "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp],
     "oq_norm_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
-    "oq_norm_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp],
+    "oq_norm_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_rope": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
     "oq_silu_mul_fwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_silu_mul_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
@@ -42,6 +42,9 @@ SIGNATURES = {
     "oq_truncate": [_vp, _i64, _f32, _vp],
     "oq_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
 }
+
+# functions returning a size instead of an error code
+SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64]}
 
 _lib = None
 
@@ -65,6 +68,10 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
+    for name, argtypes in SIZE_FUNCS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int64
     _lib = lib
     return lib
 
@@ -74,6 +81,10 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise OQError(f"{name} failed (rc={rc}): {lib.oq_last_error().decode()}")
+
+
+def size_call(name, *args):
+    return int(getattr(load(), name)(*args))
 
 
 def dt(t):

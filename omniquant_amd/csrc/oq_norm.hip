@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(1024) norm_fwd_kernel(const T* x, int64_t rows
 template <typename T>
 __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, int64_t rows, int64_t cols,
                                                        const float* w, const float* rstd_in, const float* mean_in,
-                                                       int ln, T* gx, float* gw, float* gb) {
+                                                       int ln, T* gx, float* ws, int want_b) {
     __shared__ float red[16];
     const int t = threadIdx.x, BT = blockDim.x;
     float aw[MAXCH][8], ab[MAXCH][8];
@@ -122,18 +122,31 @@ __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, 
             Vec8<T>::store(gx + r * cols + c0, o);
         }
     }
+    float* pw = ws + (int64_t)blockIdx.x * cols;
+    float* pb = ws + ((int64_t)gridDim.x + blockIdx.x) * cols;
 #pragma unroll
     for (int j = 0; j < MAXCH; ++j) {
         const int64_t c0 = ((int64_t)j * BT + t) * 8;
         if (c0 < cols) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (gw) atomicAdd(gw + c0 + i, aw[j][i]);
-                if (gb) atomicAdd(gb + c0 + i, ab[j][i]);
-            }
+            Vec8<float>::store(pw + c0, aw[j]);
+            if (want_b) Vec8<float>::store(pb + c0, ab[j]);
         }
     }
 }
+
+__global__ void __launch_bounds__(256) norm_colreduce_kernel(const float* part, int nblocks, int64_t cols, float* out) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wid = threadIdx.x >> 6;
+    __shared__ float red[4][64];
+    float acc = 0.f;
+    if (c < cols)
+        for (int b = wid; b < nblocks; b += 4) acc += part[(int64_t)b * cols + c];
+    red[wid][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (wid == 0 && c < cols) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+constexpr int64_t NORM_BWD_BLOCKS = 512;
 
 int norm_threads(int64_t cols) {
     const int64_t lanes = (cols + 7) / 8;
@@ -169,23 +182,35 @@ extern "C" int oq_norm_fwd(const void* x, int dtype, int64_t rows, int64_t cols,
 
 extern "C" int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t rows, int64_t cols, const float* w,
                            const float* rstd, const float* mean, int is_layernorm, void* gx, float* gw, float* gb,
-                           void* stream) {
+                           float* workspace, int64_t workspace_floats, void* stream) {
     OQ_CHECK_ARG(x && gy && gx && w && rstd, "oq_norm_bwd: null pointer");
     OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 512 * MAXCH, "oq_norm_bwd: cols %lld", (long long)cols);
     int bt = norm_threads(cols);
     if (bt > 512) bt = 512;
-    const int64_t grid = rows < 512 ? rows : 512;
+    const int64_t grid = rows < NORM_BWD_BLOCKS ? rows : NORM_BWD_BLOCKS;
+    OQ_CHECK_ARG(gw && workspace && workspace_floats >= 2 * grid * cols, "oq_norm_bwd: gw and a workspace of %lld floats are required",
+                 (long long)(2 * grid * cols));
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OQ_F32)
         hipLaunchKernelGGL((norm_bwd_kernel<float>), dim3(grid), dim3(bt), 0, st, (const float*)x, (const float*)gy, rows,
-                           cols, w, rstd, mean, is_layernorm, (float*)gx, gw, gb);
+                           cols, w, rstd, mean, is_layernorm, (float*)gx, workspace, gb ? 1 : 0);
     else if (dtype == OQ_BF16)
         hipLaunchKernelGGL((norm_bwd_kernel<bf16_t>), dim3(grid), dim3(bt), 0, st, (const bf16_t*)x, (const bf16_t*)gy,
-                           rows, cols, w, rstd, mean, is_layernorm, (bf16_t*)gx, gw, gb);
+                           rows, cols, w, rstd, mean, is_layernorm, (bf16_t*)gx, workspace, gb ? 1 : 0);
     else {
         oq_set_error("oq_norm_bwd: dtype %d", dtype);
         return OQ_E_UNSUPPORTED;
     }
+    if (dtype == OQ_F32 || dtype == OQ_BF16) {
+        const dim3 rg((unsigned)((cols + 63) / 64));
+        hipLaunchKernelGGL(norm_colreduce_kernel, rg, dim3(256), 0, st, workspace, (int)grid, cols, gw);
+        if (gb) hipLaunchKernelGGL(norm_colreduce_kernel, rg, dim3(256), 0, st, workspace + grid * cols, (int)grid, cols, gb);
+    }
     OQ_CHECK_LAUNCH("oq_norm_bwd");
     return OQ_OK;
+}
+
+extern "C" int64_t oq_norm_bwd_workspace(int64_t rows, int64_t cols) {
+    const int64_t grid = rows < NORM_BWD_BLOCKS ? rows : NORM_BWD_BLOCKS;
+    return 2 * grid * cols;
 }

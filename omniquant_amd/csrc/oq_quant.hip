@@ -12,6 +12,7 @@
 namespace {
 
 constexpr int MAXCH = 4;   // chunks of 8 elements per thread
+constexpr int64_t OQ_FQ_BWD_MAX_BLOCKS = 512;
 
 struct FQ {
     const void* w;
@@ -27,6 +28,7 @@ struct FQ {
     float *g_up, *g_low;
     void* gx;
     float *g_col_mul, *g_shift, *g_row_div, *g_row_mul;
+    float* ws;   // bwd workspace: [2][gridDim.x][cols] per-workgroup column partials
 };
 
 // block-wide reduction of up to 3 values; op: 0 sum, 1 max, 2 min.  All threads must call.
@@ -176,7 +178,7 @@ __global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
         for (int j = 0; j < MAXCH; ++j) {
             if (!valid[j]) continue;
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
-            const int64_t sidx = r * nseg + c0 / p.seg;
+            const int64_t sidx = r * nseg + (int64_t)((uint32_t)c0 / (uint32_t)p.seg);
             float h = hi[j], l = lo[j];
             if (bad[j] != 0.f) { h = NAN; l = NAN; }
             const QP q = make_qp(h, l, p.up, p.low, sidx, p.nbits, p.symmetric);
@@ -283,7 +285,7 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
             gs[j] = 0.f; nhi[j] = 0.f; nlo[j] = 0.f;
             if (valid[j]) {
                 const int64_t c0 = ((int64_t)j * BT + t) * 8;
-                qp[j] = make_qp(hi[j], lo[j], p.up, p.low, r * nseg + c0 / p.seg, p.nbits, p.symmetric);
+                qp[j] = make_qp(hi[j], lo[j], p.up, p.low, r * nseg + (int64_t)((uint32_t)c0 / (uint32_t)p.seg), p.nbits, p.symmetric);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float tq = x[j][i] / qp[j].s;
@@ -318,7 +320,7 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
         for (int j = 0; j < MAXCH; ++j) {
             if (!valid[j]) continue;
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
-            const int64_t sidx = r * nseg + c0 / p.seg;
+            const int64_t sidx = r * nseg + (int64_t)((uint32_t)c0 / (uint32_t)p.seg);
             const QP q = qp[j];
             float ds_dhs, ds_dls;   // d scale / d hi', d scale / d lo'
             if (p.symmetric) {
@@ -384,19 +386,32 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
     }
     if constexpr (LET) {
       if (p.g_col_mul || p.g_shift) {
+        // per-workgroup partial column sums -> workspace (plain coalesced stores); colreduce_kernel finishes.
+        float* wcm = p.ws + (int64_t)blockIdx.x * p.cols;
+        float* wsh = p.ws + ((int64_t)gridDim.x + blockIdx.x) * p.cols;
 #pragma unroll
         for (int j = 0; j < MAXCH; ++j) {
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             if (c0 < p.cols) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if (p.g_col_mul) atomicAdd(p.g_col_mul + c0 + i, acc_cm[j][i]);
-                    if (p.g_shift) atomicAdd(p.g_shift + c0 + i, acc_sh[j][i]);
-                }
+                if (p.g_col_mul) Vec8<float>::store(wcm + c0, acc_cm[j]);
+                if (p.g_shift) Vec8<float>::store(wsh + c0, acc_sh[j]);
             }
         }
       }
     }
+}
+
+// out[c] = sum_b part[b][c]   (deterministic: fixed order, no atomics)
+__global__ void __launch_bounds__(256) colreduce_kernel(const float* part, int nblocks, int64_t cols, float* out) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+    const int wid = threadIdx.x >> 6;
+    __shared__ float red[4][64];
+    float acc = 0.f;
+    if (c < cols)
+        for (int b = wid; b < nblocks; b += 4) acc += part[(int64_t)b * cols + c];
+    red[wid][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (wid == 0 && c < cols) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 int block_threads(int64_t cols) {
@@ -477,7 +492,8 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
                                 int symmetric, const float* col_mul, const float* row_div, const float* row_mul,
                                 const float* shift, const float* up, const float* low, const void* g, int g_dtype,
                                 const float* g_wshift, float* g_up, float* g_low, void* gx, int gx_dtype,
-                                float* g_col_mul, float* g_shift, float* g_row_div, float* g_row_mul, void* stream) {
+                                float* g_col_mul, float* g_shift, float* g_row_div, float* g_row_mul,
+                                float* workspace, int64_t workspace_floats, void* stream) {
     int rc = check_shape("oq_fakequant_bwd", rows, cols, seg, nbits);
     if (rc) return rc;
     OQ_CHECK_ARG(w && g, "oq_fakequant_bwd: null w/g");
@@ -495,8 +511,13 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
     p.g_col_mul = g_col_mul; p.g_shift = g_shift; p.g_row_div = g_row_div; p.g_row_mul = g_row_mul;
     const int bt = block_threads(cols);
     // column accumulators are flushed once per workgroup: keep the grid small when they are live
-    const int64_t cap = (g_col_mul || g_shift) ? 1024 : 8192;
+    const int64_t cap = (g_col_mul || g_shift) ? OQ_FQ_BWD_MAX_BLOCKS : 8192;
     const int64_t grid = rows < cap ? rows : cap;
+    if (g_col_mul || g_shift) {
+        OQ_CHECK_ARG(workspace && workspace_floats >= 2 * grid * cols,
+                     "oq_fakequant_bwd: workspace of %lld floats needed (oq_fakequant_bwd_workspace)", (long long)(2 * grid * cols));
+        p.ws = workspace;
+    }
     const bool let = g_col_mul || g_shift || g_row_div || g_row_mul;
     const int key = w_dtype * 3 + g_dtype;
     switch (key) {
@@ -510,6 +531,16 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
             oq_set_error("oq_fakequant_bwd: unsupported dtype pair w=%d g=%d", w_dtype, g_dtype);
             return OQ_E_UNSUPPORTED;
     }
+    if (g_col_mul || g_shift) {
+        const dim3 rg((unsigned)((cols + 63) / 64));
+        if (g_col_mul) hipLaunchKernelGGL(colreduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace, (int)grid, cols, g_col_mul);
+        if (g_shift) hipLaunchKernelGGL(colreduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace + grid * cols, (int)grid, cols, g_shift);
+    }
     OQ_CHECK_LAUNCH("oq_fakequant_bwd");
     return OQ_OK;
+}
+
+extern "C" int64_t oq_fakequant_bwd_workspace(int64_t rows, int64_t cols) {
+    const int64_t grid = rows < OQ_FQ_BWD_MAX_BLOCKS ? rows : OQ_FQ_BWD_MAX_BLOCKS;
+    return 2 * grid * cols;
 }

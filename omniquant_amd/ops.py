@@ -72,18 +72,22 @@ class FakeQuantFn(torch.autograd.Function):
         g_up = torch.empty((nseg, 1), dtype=torch.float32, device=dev) if need[5] else None
         g_low = torch.empty((nseg, 1), dtype=torch.float32, device=dev) if need[6] else None
         gx = torch.empty(w.shape, dtype=gy.dtype, device=dev) if need[0] else None
-        g_cm = torch.zeros((cols,), dtype=torch.float32, device=dev) if need[1] else None
+        g_cm = torch.empty((cols,), dtype=torch.float32, device=dev) if need[1] else None
         g_rd = torch.empty((rows,), dtype=torch.float32, device=dev) if need[2] else None
         g_rm = torch.empty((rows,), dtype=torch.float32, device=dev) if need[3] else None
         g_sh = None
         gws = None
         if need[4] and ctx.has_wshift:
-            g_sh = torch.zeros((cols,), dtype=torch.float32, device=dev)
+            g_sh = torch.empty((cols,), dtype=torch.float32, device=dev)
             gws = gwshift.contiguous().float() if gwshift is not None else torch.zeros((rows,), device=dev)
+        ws, ws_n = None, 0
+        if g_cm is not None or g_sh is not None:
+            ws_n = C.size_call("oq_fakequant_bwd_workspace", rows, cols)
+            ws = torch.empty((ws_n,), dtype=torch.float32, device=dev)
         C.call("oq_fakequant_bwd", C.ptr(w), C.dt(w), rows, cols, seg, nbits, symmetric,
                C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l),
                C.ptr(gy), C.dt(gy), C.fptr(gws), C.fptr(g_up), C.fptr(g_low), C.ptr(gx), C.dt(gy),
-               C.fptr(g_cm), C.fptr(g_sh), C.fptr(g_rd), C.fptr(g_rm), C.stream())
+               C.fptr(g_cm), C.fptr(g_sh), C.fptr(g_rd), C.fptr(g_rm), C.fptr(ws), ws_n, C.stream())
         if gx is not None and gx.dtype != w.dtype:
             gx = gx.to(w.dtype)
         return gx, g_cm, g_rd, g_rm, g_sh, g_up, g_low, None, None, None, None, None
@@ -93,6 +97,18 @@ def fake_quant(x, nbits, seg=None, up=None, low=None, symmetric=False, out_dtype
                col_mul=None, row_div=None, row_mul=None, shift=None):
     """Functional entry: returns y (and wshift when `shift` is given)."""
     seg = seg or x.shape[-1]
+    if (seg == x.shape[-1] and seg <= 512 and col_mul is None and row_div is None and row_mul is None
+            and shift is None and up is None):
+        # short rows (per-head quantisation over head_dim): pack several segments into one kernel row so a
+        # workgroup streams 2-8 KB instead of 256 B; segments never straddle rows, results are identical.
+        nrows = x.numel() // seg
+        m = 1
+        while seg * m * 2 <= 4096 and nrows % (m * 2) == 0:
+            m *= 2
+        if m > 1:
+            y, _ = FakeQuantFn.apply(x.contiguous().view(nrows // m, seg * m), None, None, None, None, None, None,
+                                     nbits, seg, symmetric, out_dtype or x.dtype, stash)
+            return y.view(x.shape)
     y, wshift = FakeQuantFn.apply(x, col_mul, row_div, row_mul, shift, up, low, nbits, seg, symmetric,
                                   out_dtype or x.dtype, stash)
     return (y, wshift) if shift is not None else y
@@ -264,11 +280,13 @@ class NormFn(torch.autograd.Function):
         cols = x.shape[-1]
         rows = x.numel() // cols
         gx = torch.empty_like(x)
-        gw = torch.zeros((cols,), dtype=torch.float32, device=x.device) if ctx.needs_input_grad[1] else None
-        gb = torch.zeros((cols,), dtype=torch.float32, device=x.device) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        gw = torch.empty((cols,), dtype=torch.float32, device=x.device)
+        gb = torch.empty((cols,), dtype=torch.float32, device=x.device) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        ws_n = C.size_call("oq_norm_bwd_workspace", rows, cols)
+        ws = torch.empty((ws_n,), dtype=torch.float32, device=x.device)
         C.call("oq_norm_bwd", C.ptr(x), C.ptr(gy), C.dt(x), rows, cols, C.fptr(w32), C.fptr(rstd), C.fptr(mean),
-               int(ctx.is_ln), C.ptr(gx), C.fptr(gw), C.fptr(gb), C.stream())
-        return gx, gw, gb, None, None
+               int(ctx.is_ln), C.ptr(gx), C.fptr(gw), C.fptr(gb), C.fptr(ws), ws_n, C.stream())
+        return gx, (gw if ctx.needs_input_grad[1] else None), gb, None, None
 
 
 class RopeFn(torch.autograd.Function):
