@@ -124,7 +124,7 @@ def gemm_roofline(runner, quant_inps, fp_inps, cfg, n_prof=3):
                 gemm_ms_per_step=1e3 * all_t / n_prof, linear_gemm_ms_per_step=1e3 * tot_t / n_prof)
 
 
-def cpu_baseline(name, n_steps=2):
+def cpu_baseline(name, n_steps=1):
     """CPU baseline: the oracle (pure-PyTorch fp32 restatement of the reference loop, pinned to the reference by the
     golden fixtures) timed on this box's host cores on a bounded sample of the SAME workload.  Baseline only."""
     from oracle import ref_cpu as R

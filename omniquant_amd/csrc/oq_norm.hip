@@ -134,16 +134,32 @@ __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, 
     }
 }
 
-__global__ void __launch_bounds__(256) norm_colreduce_kernel(const float* part, int nblocks, int64_t cols, float* out) {
-    const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int wid = threadIdx.x >> 6;
-    __shared__ float red[4][64];
-    float acc = 0.f;
-    if (c < cols)
-        for (int b = wid; b < nblocks; b += 4) acc += part[(int64_t)b * cols + c];
-    red[wid][threadIdx.x & 63] = acc;
+__global__ void __launch_bounds__(256) norm_colreduce_kernel(const float* part, int nblocks, int64_t cols, float* out0,
+                                                             float* out1) {
+    const float* src = part + (int64_t)blockIdx.y * nblocks * cols;
+    float* out = blockIdx.y == 0 ? out0 : out1;
+    if (!out) return;
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int64_t c = (int64_t)blockIdx.x * 16 + cl;
+    __shared__ float red[16][17];
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    if (c < cols) {
+        for (int b0 = rg * 8; b0 < nblocks; b0 += 128) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (b0 + k < nblocks) a[k] += src[(int64_t)(b0 + k) * cols + c];
+        }
+    }
+    red[rg][cl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
-    if (wid == 0 && c < cols) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rg == 0 && c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][cl];
+        out[c] = s;
+    }
 }
 
 constexpr int64_t NORM_BWD_BLOCKS = 512;
@@ -202,9 +218,8 @@ extern "C" int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t row
         return OQ_E_UNSUPPORTED;
     }
     if (dtype == OQ_F32 || dtype == OQ_BF16) {
-        const dim3 rg((unsigned)((cols + 63) / 64));
-        hipLaunchKernelGGL(norm_colreduce_kernel, rg, dim3(256), 0, st, workspace, (int)grid, cols, gw);
-        if (gb) hipLaunchKernelGGL(norm_colreduce_kernel, rg, dim3(256), 0, st, workspace + grid * cols, (int)grid, cols, gb);
+        const dim3 rg((unsigned)((cols + 15) / 16), gb ? 2 : 1);
+        hipLaunchKernelGGL(norm_colreduce_kernel, rg, dim3(256), 0, st, workspace, (int)grid, cols, gw, gb);
     }
     OQ_CHECK_LAUNCH("oq_norm_bwd");
     return OQ_OK;

@@ -11,7 +11,6 @@
 
 namespace {
 
-constexpr int MAXCH = 4;   // chunks of 8 elements per thread
 constexpr int64_t OQ_FQ_BWD_MAX_BLOCKS = 512;
 
 struct FQ {
@@ -96,8 +95,8 @@ __device__ __forceinline__ QP make_qp(float hi, float lo, const float* up, const
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <typename TIN, typename TOUT>
-__global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
+template <typename TIN, typename TOUT, int CH>
+__global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_fwd_kernel(FQ p) {
     __shared__ float red[3 * 16];
     const int t = threadIdx.x, BT = blockDim.x;
     const bool small = p.seg <= 512;
@@ -108,13 +107,13 @@ __global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
 
     for (int64_t r = blockIdx.x; r < p.rows; r += gridDim.x) {
-        float x[MAXCH][8];
-        bool valid[MAXCH];
+        float x[CH][8];
+        bool valid[CH];
         float dot = 0.f;
         const float rd = p.row_div ? p.row_div[r] : 1.f;
         const float rm = p.row_mul ? p.row_mul[r] : 1.f;
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < CH; ++j) {
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             valid[j] = c0 < p.cols;
             if (valid[j]) {
@@ -138,9 +137,9 @@ __global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
             }
         }
         // ---- min / max (NaN-propagating like torch.amax/amin) ---------------------------------
-        float hi[MAXCH], lo[MAXCH], bad[MAXCH];
+        float hi[CH], lo[CH], bad[CH];
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < CH; ++j) {
             hi[j] = -INFINITY;
             lo[j] = INFINITY;
             bad[j] = 0.f;
@@ -155,7 +154,7 @@ __global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
         }
         if (small) {
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j) {
+            for (int j = 0; j < CH; ++j) {
                 hi[j] = wave_max(hi[j], lps);
                 lo[j] = wave_min(lo[j], lps);
                 bad[j] = wave_max(bad[j], lps);
@@ -163,7 +162,7 @@ __global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
         } else {
             float v[3] = {-INFINITY, INFINITY, 0.f};
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j) {
+            for (int j = 0; j < CH; ++j) {
                 v[0] = fmaxf(v[0], hi[j]);
                 v[1] = fminf(v[1], lo[j]);
                 v[2] = fmaxf(v[2], bad[j]);
@@ -171,11 +170,11 @@ __global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
             const int op[3] = {1, 2, 1};
             block_reduce<3>(v, op, red);
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j) { hi[j] = v[0]; lo[j] = v[1]; bad[j] = v[2]; }
+            for (int j = 0; j < CH; ++j) { hi[j] = v[0]; lo[j] = v[1]; bad[j] = v[2]; }
         }
         // ---- quantise ---------------------------------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < CH; ++j) {
             if (!valid[j]) continue;
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             const int64_t sidx = r * nseg + (int64_t)((uint32_t)c0 / (uint32_t)p.seg);
@@ -210,8 +209,8 @@ __global__ void __launch_bounds__(1024) fq_fwd_kernel(FQ p) {
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
-template <typename TIN, typename TG, bool LET, int MAXT>
-__global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
+template <typename TIN, typename TG, bool LET, int CH>
+__global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_bwd_kernel(FQ p) {
     __shared__ float red[3 * 16];
     const int t = threadIdx.x, BT = blockDim.x;
     const bool small = p.seg <= 512;
@@ -225,7 +224,7 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
     const bool need_gx = p.gx || need_let;
     const bool need_sh = LET && p.g_shift;
 
-    constexpr int NACC = LET ? MAXCH : 1;
+    constexpr int NACC = LET ? CH : 1;
     float acc_cm[NACC][8], acc_sh[NACC][8];
 #pragma unroll
     for (int j = 0; j < NACC; ++j)
@@ -233,13 +232,14 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
         for (int i = 0; i < 8; ++i) { acc_cm[j][i] = 0.f; acc_sh[j][i] = 0.f; }
 
     for (int64_t r = blockIdx.x; r < p.rows; r += gridDim.x) {
-        float w[MAXCH][8], x[MAXCH][8], G[MAXCH][8];
-        bool valid[MAXCH];
+        float w[CH][8], x[CH][8], G[CH][8];
+        bool valid[CH];
         const float rd = p.row_div ? p.row_div[r] : 1.f;
         const float rm = p.row_mul ? p.row_mul[r] : 1.f;
+        const float inv_rd = 1.f / rd;      // gradient path only: reciprocal multiplies instead of IEEE divides
         const float gws = p.g_wshift ? p.g_wshift[r] : 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < CH; ++j) {
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             valid[j] = c0 < p.cols;
             if (valid[j]) {
@@ -249,15 +249,15 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
                 for (int i = 0; i < 8; ++i) {
                     float v = w[j][i];
                     if (p.col_mul) v = v * p.col_mul[c0 + i];
-                    if (p.row_div) v = v / rd;
-                    if (p.row_mul) v = v * rm;
+                    if (p.row_div) v = v / rd;        // keep the IEEE divide: x must equal the forward's x bit for bit
+                    if (p.row_mul) v = v * rm;        // (ties with hi/lo and the clip mask depend on it)
                     x[j][i] = v;
                 }
             }
         }
-        float hi[MAXCH], lo[MAXCH];
+        float hi[CH], lo[CH];
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < CH; ++j) {
             hi[j] = -INFINITY;
             lo[j] = INFINITY;
             if (valid[j]) {
@@ -267,28 +267,29 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
         }
         if (small) {
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j) { hi[j] = wave_max(hi[j], lps); lo[j] = wave_min(lo[j], lps); }
+            for (int j = 0; j < CH; ++j) { hi[j] = wave_max(hi[j], lps); lo[j] = wave_min(lo[j], lps); }
         } else {
             float v[2] = {-INFINITY, INFINITY};
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j) { v[0] = fmaxf(v[0], hi[j]); v[1] = fminf(v[1], lo[j]); }
+            for (int j = 0; j < CH; ++j) { v[0] = fmaxf(v[0], hi[j]); v[1] = fminf(v[1], lo[j]); }
             const int op[2] = {1, 2};
             block_reduce<2>(v, op, red);
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j) { hi[j] = v[0]; lo[j] = v[1]; }
+            for (int j = 0; j < CH; ++j) { hi[j] = v[0]; lo[j] = v[1]; }
         }
         // ---- gs = sum G * d y/d s ; tie counts -------------------------------------------------
-        QP qp[MAXCH];
-        float gs[MAXCH], nhi[MAXCH], nlo[MAXCH];
+        QP qp[CH];
+        float gs[CH], nhi[CH], nlo[CH], inv_s[CH];
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < CH; ++j) {
             gs[j] = 0.f; nhi[j] = 0.f; nlo[j] = 0.f;
             if (valid[j]) {
                 const int64_t c0 = ((int64_t)j * BT + t) * 8;
                 qp[j] = make_qp(hi[j], lo[j], p.up, p.low, r * nseg + (int64_t)((uint32_t)c0 / (uint32_t)p.seg), p.nbits, p.symmetric);
+                inv_s[j] = 1.f / qp[j].s;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float tq = x[j][i] / qp[j].s;
+                    const float tq = x[j][i] * inv_s[j];
                     const float v = rne_ste(tq) + qp[j].z;
                     const bool in = (v >= 0.f) && (v <= Q);
                     const float qv = fminf(fmaxf(v, 0.f), Q);
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
         }
         if (small) {
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j) {
+            for (int j = 0; j < CH; ++j) {
                 gs[j] = wave_sum(gs[j], lps);
                 nhi[j] = wave_sum(nhi[j], lps);
                 nlo[j] = wave_sum(nlo[j], lps);
@@ -308,16 +309,16 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
         } else {
             float v[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j) { v[0] += gs[j]; v[1] += nhi[j]; v[2] += nlo[j]; }
+            for (int j = 0; j < CH; ++j) { v[0] += gs[j]; v[1] += nhi[j]; v[2] += nlo[j]; }
             const int op[3] = {0, 0, 0};
             block_reduce<3>(v, op, red);
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j) { gs[j] = v[0]; nhi[j] = v[1]; nlo[j] = v[2]; }
+            for (int j = 0; j < CH; ++j) { gs[j] = v[0]; nhi[j] = v[1]; nlo[j] = v[2]; }
         }
         // ---- d s / d hi', d s / d lo'  (hi' = su*hi, lo' = sl*lo) --------------------------------
         float acc_rd = 0.f, acc_rm = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < CH; ++j) {
             if (!valid[j]) continue;
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             const int64_t sidx = r * nseg + (int64_t)((uint32_t)c0 / (uint32_t)p.seg);
@@ -347,25 +348,26 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
             }
             if (need_gx || need_sh) {
                 float gxv[8];
+                const float tie_hi = g_hs * q.su / nhi[j], tie_lo = g_ls * q.sl / nlo[j];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float tq = x[j][i] / q.s;
+                    const float tq = x[j][i] * inv_s[j];
                     const float v = rne_ste(tq) + q.z;
                     const bool in = (v >= 0.f) && (v <= Q);
                     float gv = in ? G[j][i] : 0.f;
-                    if (x[j][i] == q.hi) gv += g_hs * q.su / nhi[j];
-                    if (x[j][i] == q.lo) gv += g_ls * q.sl / nlo[j];
+                    if (x[j][i] == q.hi) gv += tie_hi;
+                    if (x[j][i] == q.lo) gv += tie_lo;
                     gxv[i] = gv;
                     if constexpr (LET) {
                       if (need_let) {
                         // x = ((w*cm)/rd)*rm ; b = (w*cm)/rd
                         float a = w[j][i];
                         if (p.col_mul) a = a * p.col_mul[c0 + i];
-                        const float b = p.row_div ? a / rd : a;
+                        const float b = p.row_div ? a * inv_rd : a;
                         acc_rm += gv * b;
                         const float gb = p.row_mul ? gv * rm : gv;
-                        acc_rd += gb * (-b / rd);
-                        const float ga = p.row_div ? gb / rd : gb;
+                        acc_rd += gb * (-b * inv_rd);
+                        const float ga = p.row_div ? gb * inv_rd : gb;
                         acc_cm[j][i] += ga * w[j][i];
                       }
                       if (need_sh) acc_sh[j][i] += gws * w[j][i];
@@ -390,7 +392,7 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
         float* wcm = p.ws + (int64_t)blockIdx.x * p.cols;
         float* wsh = p.ws + ((int64_t)gridDim.x + blockIdx.x) * p.cols;
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < CH; ++j) {
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             if (c0 < p.cols) {
                 if (p.g_col_mul) Vec8<float>::store(wcm + c0, acc_cm[j]);
@@ -401,26 +403,46 @@ __global__ void __launch_bounds__(MAXT) fq_bwd_kernel(FQ p) {
     }
 }
 
-// out[c] = sum_b part[b][c]   (deterministic: fixed order, no atomics)
-__global__ void __launch_bounds__(256) colreduce_kernel(const float* part, int nblocks, int64_t cols, float* out) {
-    const int64_t c = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-    const int wid = threadIdx.x >> 6;
-    __shared__ float red[4][64];
-    float acc = 0.f;
-    if (c < cols)
-        for (int b = wid; b < nblocks; b += 4) acc += part[(int64_t)b * cols + c];
-    red[wid][threadIdx.x & 63] = acc;
+// out[c] = sum_b part[b][c]   (deterministic: fixed order, no atomics).  blockIdx.y selects the vector
+// (0: g_col_mul, 1: g_shift).  A workgroup owns 16 columns: 16 row-groups x 16 columns of lanes, 8 independent
+// accumulators per lane (8 loads in flight), then one LDS tree over the row-groups.
+__global__ void __launch_bounds__(256) colreduce_kernel(const float* part, int nblocks, int64_t cols, float* out0,
+                                                        float* out1) {
+    const float* src = part + (int64_t)blockIdx.y * nblocks * cols;
+    float* out = blockIdx.y == 0 ? out0 : out1;
+    if (!out) return;
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int64_t c = (int64_t)blockIdx.x * 16 + cl;
+    __shared__ float red[16][17];
+    float a[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = 0.f;
+    if (c < cols) {
+        for (int b0 = rg * 8; b0 < nblocks; b0 += 128) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (b0 + k < nblocks) a[k] += src[(int64_t)(b0 + k) * cols + c];
+        }
+    }
+    red[rg][cl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
-    if (wid == 0 && c < cols) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (rg == 0 && c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][cl];
+        out[c] = s;
+    }
 }
 
-int block_threads(int64_t cols) {
-    const int64_t lanes = (cols + 7) / 8;   // lanes needed with one chunk each
-    if (lanes <= 64) return 64;
-    if (lanes <= 128) return 128;
-    if (cols <= 8 * 256 * MAXCH) return 256;
-    if (cols <= 8 * 512 * MAXCH) return 512;
-    return 1024;
+// chunks per thread (1, 4 or 8) and threads per workgroup for a row of `cols` elements: as many waves as the row
+// allows (one 16-byte chunk per lane) before giving a lane more than one chunk.
+void row_geometry(int64_t cols, int* ch, int* bt) {
+    const int64_t lanes = (cols + 7) / 8;
+    int c = lanes <= 1024 ? 1 : (lanes <= 2048 ? 4 : 8);     // CH=1: <=1024 threads; CH=4/8: <=512 threads
+    int64_t t = (lanes + c - 1) / c;
+    t = ((t + 63) / 64) * 64;
+    *ch = c;
+    *bt = (int)t;
 }
 
 int check_shape(const char* fn, int64_t rows, int64_t cols, int64_t seg, int nbits) {
@@ -436,14 +458,18 @@ int check_shape(const char* fn, int64_t rows, int64_t cols, int64_t seg, int nbi
     } else {
         OQ_CHECK_ARG(seg == cols, "%s: seg %lld > 512 must equal cols %lld", fn, (long long)seg, (long long)cols);
     }
-    OQ_CHECK_ARG(cols <= 8 * 1024 * MAXCH, "%s: cols %lld exceeds %d", fn, (long long)cols, 8 * 1024 * MAXCH);
+    OQ_CHECK_ARG(cols <= 8 * 1024 * 4, "%s: cols %lld exceeds %d", fn, (long long)cols, 8 * 1024 * 4);
     return OQ_OK;
 }
 
 }  // namespace
 
-#define FQ_DISPATCH_FWD(TIN, TOUT) \
-    hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p)
+#define FQ_DISPATCH_FWD(TIN, TOUT)                                                                              \
+    do {                                                                                                        \
+        if (ch == 1) hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, 1>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);      \
+        else if (ch == 4) hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, 4>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p); \
+        else hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, 8>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);              \
+    } while (0)
 
 extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits,
                                 int symmetric, const float* col_mul, const float* row_div, const float* row_mul,
@@ -459,7 +485,8 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     p.w = w; p.rows = rows; p.cols = cols; p.seg = seg; p.nbits = nbits; p.symmetric = symmetric;
     p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = wshift ? shift : nullptr;
     p.up = up; p.low = low; p.y = y; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax; p.wshift = wshift;
-    const int bt = block_threads(cols);
+    int ch, bt;
+    row_geometry(cols, &ch, &bt);
     const int64_t grid = rows < 8192 ? rows : 8192;
     const int key = w_dtype * 3 + y_dtype;
     switch (key) {
@@ -467,9 +494,7 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
         case OQ_F32 * 3 + OQ_BF16: FQ_DISPATCH_FWD(float, bf16_t); break;
         case OQ_F16 * 3 + OQ_F32: FQ_DISPATCH_FWD(f16_t, float); break;
         case OQ_F16 * 3 + OQ_BF16: FQ_DISPATCH_FWD(f16_t, bf16_t); break;
-        case OQ_F16 * 3 + OQ_F16: FQ_DISPATCH_FWD(f16_t, f16_t); break;
         case OQ_BF16 * 3 + OQ_BF16: FQ_DISPATCH_FWD(bf16_t, bf16_t); break;
-        case OQ_BF16 * 3 + OQ_F32: FQ_DISPATCH_FWD(bf16_t, float); break;
         default:
             oq_set_error("oq_fakequant_fwd: unsupported dtype pair in=%d out=%d", w_dtype, y_dtype);
             return OQ_E_UNSUPPORTED;
@@ -478,14 +503,18 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     return OQ_OK;
 }
 
-#define FQ_DISPATCH_BWD(TIN, TG)                                                                                  \
-    do {                                                                                                          \
-        if (bt > 512)                                                                                             \
-            hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, true, 1024>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);  \
-        else if (let)                                                                                             \
-            hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, true, 512>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);   \
-        else                                                                                                      \
-            hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, false, 512>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);  \
+#define FQ_LAUNCH_BWD(TIN, TG, L, C_) hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, L, C_>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p)
+#define FQ_DISPATCH_BWD(TIN, TG)                                     \
+    do {                                                             \
+        if (let) {                                                   \
+            if (ch == 1) FQ_LAUNCH_BWD(TIN, TG, true, 1);            \
+            else if (ch == 4) FQ_LAUNCH_BWD(TIN, TG, true, 4);       \
+            else FQ_LAUNCH_BWD(TIN, TG, true, 8);                    \
+        } else {                                                     \
+            if (ch == 1) FQ_LAUNCH_BWD(TIN, TG, false, 1);           \
+            else if (ch == 4) FQ_LAUNCH_BWD(TIN, TG, false, 4);      \
+            else FQ_LAUNCH_BWD(TIN, TG, false, 8);                   \
+        }                                                            \
     } while (0)
 
 extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits,
@@ -509,7 +538,8 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
     p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = shift; p.up = up; p.low = low;
     p.g = g; p.g_wshift = g_wshift; p.g_up = g_up; p.g_low = g_low; p.gx = gx;
     p.g_col_mul = g_col_mul; p.g_shift = g_shift; p.g_row_div = g_row_div; p.g_row_mul = g_row_mul;
-    const int bt = block_threads(cols);
+    int ch, bt;
+    row_geometry(cols, &ch, &bt);
     // column accumulators are flushed once per workgroup: keep the grid small when they are live
     const int64_t cap = (g_col_mul || g_shift) ? OQ_FQ_BWD_MAX_BLOCKS : 8192;
     const int64_t grid = rows < cap ? rows : cap;
@@ -526,15 +556,13 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
         case OQ_F16 * 3 + OQ_F32: FQ_DISPATCH_BWD(f16_t, float); break;
         case OQ_F16 * 3 + OQ_BF16: FQ_DISPATCH_BWD(f16_t, bf16_t); break;
         case OQ_BF16 * 3 + OQ_BF16: FQ_DISPATCH_BWD(bf16_t, bf16_t); break;
-        case OQ_BF16 * 3 + OQ_F32: FQ_DISPATCH_BWD(bf16_t, float); break;
         default:
             oq_set_error("oq_fakequant_bwd: unsupported dtype pair w=%d g=%d", w_dtype, g_dtype);
             return OQ_E_UNSUPPORTED;
     }
     if (g_col_mul || g_shift) {
-        const dim3 rg((unsigned)((cols + 63) / 64));
-        if (g_col_mul) hipLaunchKernelGGL(colreduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace, (int)grid, cols, g_col_mul);
-        if (g_shift) hipLaunchKernelGGL(colreduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace + grid * cols, (int)grid, cols, g_shift);
+        const dim3 rg((unsigned)((cols + 15) / 16), 2);
+        hipLaunchKernelGGL(colreduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace, (int)grid, cols, g_col_mul, g_shift);
     }
     OQ_CHECK_LAUNCH("oq_fakequant_bwd");
     return OQ_OK;

@@ -54,15 +54,23 @@ class QuantLinear(nn.Module):
     def drop_cache(self):
         self._wcache, self._wcache_key = None, None
 
-    def forward(self, input: torch.Tensor):
+    def quantize_input(self, input):
+        """Per-token fake quant of the input, exposed so that sibling projections reading the SAME tensor with
+        identical quantizer settings (q/k/v; gate/up) share one quantisation pass (reference quirk Q7: the three
+        results are bit-identical)."""
+        if self.use_act_quant and not self.disable_input_quant:
+            return self.act_quantizer(input)
+        return input
+
+    def forward(self, input: torch.Tensor, input_is_quantized: bool = False):
         if self.use_temporary_parameter:
             weight, bias = self.temp_weight, self.temp_bias
         elif self.use_weight_quant:
             weight, bias = self.weight_quantizer.quantize(self.weight, out_dtype=input.dtype), self.bias
         else:
             weight, bias = self._weight_as(input.dtype), self.bias
-        if self.use_act_quant and not self.disable_input_quant:
-            input = self.act_quantizer(input)
+        if not input_is_quantized:
+            input = self.quantize_input(input)
         return self.fwd_func(input, weight, bias, **self.fwd_kwargs)
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):

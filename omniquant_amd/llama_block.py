@@ -34,7 +34,8 @@ class QuantLlamaMLP(nn.Module):
             raise NotImplementedError(f"hidden_act {hidden_act}: only SiLU has a HIP kernel")
 
     def forward(self, x):
-        return self.down_proj(ops.SiluMulFn.apply(self.gate_proj(x), self.up_proj(x)))
+        xq = self.gate_proj.quantize_input(x)       # gate/up share one act-quant pass (identical settings)
+        return self.down_proj(ops.SiluMulFn.apply(self.gate_proj(xq, True), self.up_proj(xq, True)))
 
 
 class QuantLlamaAttention(nn.Module):
@@ -82,9 +83,10 @@ class QuantLlamaAttention(nn.Module):
             raise NotImplementedError("the calibration hot path runs without KV cache / attention outputs")
         bsz, q_len, _ = hidden_states.size()
         nh, nkv, hd = self.num_heads, self.num_key_value_heads, self.head_dim
-        q = self.q_proj(hidden_states).view(bsz, q_len, nh, hd)
-        k = self.k_proj(hidden_states).view(bsz, q_len, nkv, hd)
-        v = self.v_proj(hidden_states).view(bsz, q_len, nkv, hd)
+        hq = self.q_proj.quantize_input(hidden_states)      # q/k/v share one act-quant pass
+        q = self.q_proj(hq, True).view(bsz, q_len, nh, hd)
+        k = self.k_proj(hq, True).view(bsz, q_len, nkv, hd)
+        v = self.v_proj(hq, True).view(bsz, q_len, nkv, hd)
         cos, sin = self._rope_tables(position_ids, q_len, hidden_states.device)
         q = ops.RopeFn.apply(q, cos, sin)
         k = ops.RopeFn.apply(k, cos, sin)

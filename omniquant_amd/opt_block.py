@@ -43,10 +43,11 @@ class QuantOPTAttention(nn.Module):
             raise NotImplementedError("the calibration hot path runs self-attention without cache / head masks")
         bsz, tgt_len, _ = hidden_states.size()
         nh, hd = self.num_heads, self.head_dim
-        q = ops.ScaleFn.apply(self.q_proj(hidden_states), self.scaling)
+        hq = self.q_proj.quantize_input(hidden_states)      # q/k/v share one act-quant pass
+        q = ops.ScaleFn.apply(self.q_proj(hq, True), self.scaling)
         q = self.qkt_matmul.quant_x1(q)
-        k = self.qkt_matmul.quant_x2(self.k_proj(hidden_states))
-        v = self.pv_matmul.quant_x2(self.v_proj(hidden_states))
+        k = self.qkt_matmul.quant_x2(self.k_proj(hq, True))
+        v = self.pv_matmul.quant_x2(self.v_proj(hq, True))
         q, k, v = (t.view(bsz, tgt_len, nh, hd) for t in (q, k, v))
         scores = self.qkt_matmul.scores(q, k)
         mask = None

@@ -14,7 +14,7 @@ def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(int|const char\*)\s+(oq_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(int64_t|int|const char\*)\s+(oq_\w+)\s*\(([^)]*)\)\s*;", src):
         args = [a.strip() for a in m.group(3).split(",") if a.strip() and a.strip() != "void"]
         decls[m.group(2)] = args
     return decls
@@ -33,7 +33,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_ctypes_signatures_match_header():
     decls = _declared()
     kinds = {ctypes.c_void_p: "ptr", ctypes.c_int64: "int64_t", ctypes.c_int: "int", ctypes.c_float: "float"}
-    for name, argtypes in _capi.SIGNATURES.items():
+    for name, argtypes in list(_capi.SIGNATURES.items()) + list(_capi.SIZE_FUNCS.items()):
         assert name in decls, f"{name} bound in _capi.py but not declared in the header"
         hargs = decls[name]
         assert len(hargs) == len(argtypes), f"{name}: header has {len(hargs)} args, binding {len(argtypes)}"
@@ -44,7 +44,8 @@ def test_ctypes_signatures_match_header():
             else:
                 assert "*" not in h and h.startswith(k + " "), f"{name}: '{h}' bound as {k}"
     for name in decls:
-        assert name in _capi.SIGNATURES or name in ("oq_version", "oq_last_error"), f"{name} not bound"
+        assert name in _capi.SIGNATURES or name in _capi.SIZE_FUNCS or name in ("oq_version", "oq_last_error"), \
+            f"{name} not bound"
 
 
 def test_missing_gpu_is_loud():
