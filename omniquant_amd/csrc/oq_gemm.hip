@@ -31,7 +31,7 @@ struct GemmP {
     int a_kc, b_kc;
     float alpha;
     int64_t batch_i, sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
-    int tiles_n;
+    int tiles_n, tiles_m, nmajor;
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -59,6 +59,33 @@ __device__ __forceinline__ void load_tile(const bf16_t* base, int64_t ld, int64_
         }
         r[p] = v;
     }
+}
+
+// FAST path: row/column clamped once outside the K loop (out-of-range rows re-read the last valid row; their
+// products only reach output rows/cols that are never stored), K % 64 == 0 guaranteed by the host: no predication,
+// no per-iteration address arithmetic beyond one add.
+template <bool KC>
+__device__ __forceinline__ void tile_offsets(int64_t ld, int64_t i0, int64_t I, int tid, int64_t (&off)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        if (KC) {
+            int64_t i = i0 + (tid >> 3) + 32 * p;
+            i = i < I ? i : I - 1;
+            off[p] = i * ld + (tid & 7) * 8;
+        } else {
+            int64_t i = i0 + (tid & 15) * 8;
+            i = i < I ? i : I - 8;
+            off[p] = (int64_t)((tid >> 4) + 16 * p) * ld + i;
+        }
+    }
+}
+
+template <bool KC>
+__device__ __forceinline__ void load_tile_fast(const bf16_t* base, int64_t ld, int64_t k0, const int64_t (&off)[4],
+                                               u32x4 (&r)[4]) {
+    const int64_t step = KC ? k0 : k0 * ld;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) r[p] = *reinterpret_cast<const u32x4*>(base + off[p] + step);
 }
 
 template <bool KC>
@@ -100,13 +127,22 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int row0, int ks, i
     }
 }
 
-template <bool AKC, bool BKC, typename TOUT>
+template <bool AKC, bool BKC, typename TOUT, bool FAST>
 __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int tile = blockIdx.x;
-    const int64_t m0 = (int64_t)(tile / p.tiles_n) * BM, n0 = (int64_t)(tile % p.tiles_n) * BN;
+    // XCD-aware tile mapping: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so
+    // give every XCD a CONTIGUOUS range of tiles, ordered so that the range splits the larger operand (bijective
+    // for any grid size).
+    int tile;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    int64_t m0, n0;
+    if (p.nmajor) { n0 = (int64_t)(tile / p.tiles_m) * BN; m0 = (int64_t)(tile % p.tiles_m) * BM; }
+    else { m0 = (int64_t)(tile / p.tiles_n) * BM; n0 = (int64_t)(tile % p.tiles_n) * BN; }
     const int64_t bo = blockIdx.z / p.batch_i, bi = blockIdx.z % p.batch_i;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.a) + bo * p.sa_o + bi * p.sa_i;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.b) + bo * p.sb_o + bi * p.sb_i;
@@ -120,8 +156,16 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmP p) {
 
     u32x4 ra[4], rb[4];
     const int64_t nt = (p.K + BK - 1) / BK;
-    load_tile<AKC>(A, p.lda, m0, 0, p.M, p.K, tid, ra);
-    load_tile<BKC>(B, p.ldb, n0, 0, p.N, p.K, tid, rb);
+    int64_t offa[4], offb[4];
+    if (FAST) {
+        tile_offsets<AKC>(p.lda, m0, p.M, tid, offa);
+        tile_offsets<BKC>(p.ldb, n0, p.N, tid, offb);
+        load_tile_fast<AKC>(A, p.lda, 0, offa, ra);
+        load_tile_fast<BKC>(B, p.ldb, 0, offb, rb);
+    } else {
+        load_tile<AKC>(A, p.lda, m0, 0, p.M, p.K, tid, ra);
+        load_tile<BKC>(B, p.ldb, n0, 0, p.N, p.K, tid, rb);
+    }
     store_tile<AKC>(smem, tid, ra);
     store_tile<BKC>(smem + TILE_BYTES, tid, rb);
     __syncthreads();
@@ -129,8 +173,13 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmP p) {
     for (int64_t t = 0; t < nt; ++t) {
         const bool more = t + 1 < nt;
         if (more) {
-            load_tile<AKC>(A, p.lda, m0, (t + 1) * BK, p.M, p.K, tid, ra);
-            load_tile<BKC>(B, p.ldb, n0, (t + 1) * BK, p.N, p.K, tid, rb);
+            if (FAST) {
+                load_tile_fast<AKC>(A, p.lda, (t + 1) * BK, offa, ra);
+                load_tile_fast<BKC>(B, p.ldb, (t + 1) * BK, offb, rb);
+            } else {
+                load_tile<AKC>(A, p.lda, m0, (t + 1) * BK, p.M, p.K, tid, ra);
+                load_tile<BKC>(B, p.ldb, n0, (t + 1) * BK, p.N, p.K, tid, rb);
+            }
         }
         const char* sa = smem + cur * 2 * TILE_BYTES;
         const char* sb = sa + TILE_BYTES;
@@ -141,12 +190,14 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmP p) {
             for (int i = 0; i < 4; ++i) fa[i] = read_frag<AKC>(sa, wm * 64 + i * 16, ks, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j] = read_frag<BKC>(sb, wn * 64 + j * 16, ks, lane);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     // swapped operands: D[row = n-sub][col = m-sub]
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
         if (more) {
             char* da = smem + (cur ^ 1) * 2 * TILE_BYTES;
@@ -287,8 +338,16 @@ extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias
                      (long long)N, (long long)K);
         const int64_t tm = (M + BM - 1) / BM, tn = (N + BN - 1) / BN;
         p.tiles_n = (int)tn;
+        p.tiles_m = (int)tm;
+        p.nmajor = N >= M ? 1 : 0;
         dim3 grid((unsigned)(tm * tn), 1, (unsigned)(batch_o * batch_i));
-#define LAUNCH_BF16(AK, BK_, T) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T>), grid, dim3(256), 0, st, p)
+        // fast path: no predication in the K loop (row clamping needs at least one full vector per operand)
+        const bool fast = (K % BK == 0) && M >= 8 && N >= 8;
+#define LAUNCH_BF16(AK, BK_, T)                                                                         \
+    do {                                                                                                \
+        if (fast) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T, true>), grid, dim3(256), 0, st, p);  \
+        else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T, false>), grid, dim3(256), 0, st, p);      \
+    } while (0)
         const int key = (a_kc ? 4 : 0) | (b_kc ? 2 : 0) | (out_dtype == OQ_F32 ? 1 : 0);
         switch (key) {
             case 0: LAUNCH_BF16(false, false, bf16_t); break;
