@@ -90,24 +90,83 @@ struct Vec8<f16_t> {
     }
 };
 
+// ---- raw (not yet converted) 8-element vectors: lets a kernel keep the NEXT row's loads in flight in few VGPRs --
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<float> {
+    f32x4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4*>(p);
+        b = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = a[i]; v[4 + i] = b[i]; }
+    }
+};
+template <>
+struct Raw8<bf16_t> {
+    u32x4 a;
+    __device__ __forceinline__ void load(const bf16_t* p) { a = *reinterpret_cast<const u32x4*>(p); }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __builtin_bit_cast(float, a[i] << 16);
+            v[2 * i + 1] = __builtin_bit_cast(float, a[i] & 0xffff0000u);
+        }
+    }
+};
+template <>
+struct Raw8<f16_t> {
+    typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+    h8 a;
+    __device__ __forceinline__ void load(const f16_t* p) { a = *reinterpret_cast<const h8*>(p); }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+};
+
 template <typename T>
 __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
 template <typename T>
 __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
 
 // ---- wave-level reductions (width = power of two <= 64, lanes grouped contiguously) -------------
-__device__ __forceinline__ float wave_sum(float v, int width = 64) {
-    for (int m = width >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+// Butterfly on DPP (quad_perm / row_half_mirror / row_mirror: 1 VALU op each, no LDS crossbar), ds_swizzle for the
+// 16<->16 step and two v_readlane for the 32<->32 step.  Every lane of a group ends with the group's result.
+// (__shfl_xor lowers to ds_bpermute_b32 inside a runtime loop: ~100+ cycles per step, it dominated these kernels.)
+__device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (ctrl_sel) {
+        case 0: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, true); break;    // quad_perm [1,0,3,2]
+        case 1: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, true); break;    // quad_perm [2,3,0,1]
+        case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, true); break;   // row_half_mirror
+        case 3: r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, true); break;   // row_mirror
+        default: r = __builtin_amdgcn_ds_swizzle(x, 0x401F); break;                    // lane ^ 16
+    }
+    return __builtin_bit_cast(float, r);
 }
-__device__ __forceinline__ float wave_max(float v, int width = 64) {
-    for (int m = width >> 1; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_min(float v, int width = 64) {
-    for (int m = width >> 1; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
-    return v;
-}
+#define OQ_WAVE_REDUCE(NAME, OP)                                                              \
+    __device__ __forceinline__ float NAME(float v, int width = 64) {                          \
+        if (width >= 2) { const float o = dpp_f(v, 0); v = OP(v, o); }                         \
+        if (width >= 4) { const float o = dpp_f(v, 1); v = OP(v, o); }                         \
+        if (width >= 8) { const float o = dpp_f(v, 2); v = OP(v, o); }                         \
+        if (width >= 16) { const float o = dpp_f(v, 3); v = OP(v, o); }                        \
+        if (width >= 32) { const float o = dpp_f(v, 4); v = OP(v, o); }                        \
+        if (width >= 64) {                                                                     \
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));   \
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));  \
+            v = OP(a, b);                                                                      \
+        }                                                                                      \
+        return v;                                                                              \
+    }
+__device__ __forceinline__ float oq_addf(float a, float b) { return a + b; }
+OQ_WAVE_REDUCE(wave_sum, oq_addf)
+OQ_WAVE_REDUCE(wave_max, fmaxf)
+OQ_WAVE_REDUCE(wave_min, fminf)
 // NaN-propagating variants: torch.amax/amin propagate NaN, fmaxf does not.
 __device__ __forceinline__ float nmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
 __device__ __forceinline__ float nmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }

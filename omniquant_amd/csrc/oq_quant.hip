@@ -7,11 +7,13 @@
 // waves for whole-row segments), quantised and written once.  Column-wise LET gradients are accumulated in
 // registers across the rows a workgroup walks (lane -> column mapping is fixed) and flushed with one float
 // atomic per column per workgroup.
+#include <stdlib.h>
 #include "oq_common.h"
 
 namespace {
 
-constexpr int64_t OQ_FQ_BWD_MAX_BLOCKS = 512;
+constexpr int64_t OQ_FQ_BWD_MAX_BLOCKS = 512;   // workgroups when column partials are written
+constexpr int64_t OQ_FQ_MAX_BLOCKS = 1024;      // otherwise: >= 2-4 rows per workgroup so the prefetch pipelines
 
 struct FQ {
     const void* w;
@@ -60,6 +62,29 @@ struct QP {
     float s, z, su, sl, hi, lo;
 };
 
+// x / d for the LET row factor: reciprocal + one fma-residual correction (3 VALU ops instead of the ~10-op IEEE
+// expansion whose v_div_* / v_rcp ops made these kernels VALU-bound).  Forward and backward use the SAME function,
+// so x, its min/max, ties and the clip mask are self-consistent; vs. an IEEE divide the result differs by <= 1 ulp
+// in rare cases, which is below the ulp-level differences sigmoid/exp already introduce.
+__device__ __forceinline__ float div_nr(float a, float d, float inv_d) {
+    const float q = a * inv_d;
+    const float r = fmaf(-q, d, a);
+    return fmaf(r, inv_d, q);
+}
+
+// rne(x / s) evaluated as rne(x * (1/s)) -- bit-identical to the IEEE quotient's rounding except when x/s lies within
+// ~2 ulp of a half-integer; those (rare) lanes redo the exact division, so the result equals rintf(x / s) always.
+__device__ __forceinline__ float rne_div(float x, float s, float inv_s, float* tq) {
+    float t = x * inv_s;
+    float r = rintf(t);
+    if (fabsf(t - r) > fmaf(-4e-7f, fabsf(t), 0.5f)) {
+        t = x / s;
+        r = rintf(t);
+    }
+    *tq = t;
+    return r;
+}
+
 // round_ste forward exactly as the reference composes it, (round(t) - t) + t: equals rintf(t) for every finite t
 // and turns +-inf (scale == 0, quirk Q1) into NaN like the reference does.
 __device__ __forceinline__ float rne_ste(float t) {
@@ -67,15 +92,15 @@ __device__ __forceinline__ float rne_ste(float t) {
     return (r - t) + t;
 }
 
-__device__ __forceinline__ QP make_qp(float hi, float lo, const float* up, const float* low, int64_t sidx, int nbits,
+__device__ __forceinline__ QP make_qp(float hi, float lo, bool lwc, float up_logit, float low_logit, int nbits,
                                       int symmetric) {
     QP q;
     q.hi = hi;
     q.lo = lo;
-    q.su = up ? sigmoidf_(up[sidx]) : 1.0f;
-    q.sl = low ? sigmoidf_(low[sidx]) : 1.0f;
-    const float hs = up ? q.su * hi : hi;
-    const float ls = low ? q.sl * lo : lo;
+    q.su = lwc ? sigmoidf_(up_logit) : 1.0f;
+    q.sl = lwc ? sigmoidf_(low_logit) : 1.0f;
+    const float hs = lwc ? q.su * hi : hi;
+    const float ls = lwc ? q.sl * lo : lo;
     if (symmetric) {
         const float lv = (float)((1 << (nbits - 1)) - 1);
         float s = fmaxf(fabsf(hs), fabsf(ls)) / lv;
@@ -95,8 +120,11 @@ __device__ __forceinline__ QP make_qp(float hi, float lo, const float* up, const
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <typename TIN, typename TOUT, int CH>
-__global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_fwd_kernel(FQ p) {
+// A workgroup walks rows r = blockIdx.x, +gridDim.x, ...; the NEXT row's 16-byte chunks are already in flight (raw
+// registers) while the current row is reduced and quantised, so HBM requests never drain between rows.  Everything
+// that depends only on the column (col_mul, shift, segment index) is loaded once per workgroup.
+template <typename TIN, typename TOUT, bool LET, int CH>
+__global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
     __shared__ float red[3 * 16];
     const int t = threadIdx.x, BT = blockDim.x;
     const bool small = p.seg <= 512;
@@ -106,35 +134,83 @@ __global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_fwd_kernel(FQ p) {
     const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
 
-    for (int64_t r = blockIdx.x; r < p.rows; r += gridDim.x) {
-        float x[CH][8];
-        bool valid[CH];
-        float dot = 0.f;
-        const float rd = p.row_div ? p.row_div[r] : 1.f;
-        const float rm = p.row_mul ? p.row_mul[r] : 1.f;
+    bool valid[CH];
+    int c0[CH], segi[CH];
+    constexpr int NL = LET ? CH : 1;
+    float cmv[NL][8], shv[NL][8];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        c0[j] = (j * BT + t) * 8;
+        valid[j] = c0[j] < p.cols;
+        segi[j] = (int)((uint32_t)c0[j] / (uint32_t)p.seg);
+        if constexpr (LET) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                cmv[j][i] = (valid[j] && p.col_mul) ? p.col_mul[c0[j] + i] : 1.f;
+                shv[j][i] = (valid[j] && p.shift) ? p.shift[c0[j] + i] : 0.f;
+            }
+        }
+    }
+    Raw8<TIN> nxt[CH];
+    float nup[CH], nlow[CH], nrd = 1.f, nrm = 1.f;   // next row's LWC logits / row factors, prefetched with its data
+    const bool lwc = p.up != nullptr;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { nup[j] = 0.f; nlow[j] = 0.f; }
+    int64_t r = blockIdx.x;
+    if (r < p.rows) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (valid[j]) {
+                nxt[j].load(wbase + r * p.cols + c0[j]);
+                if (lwc) { nup[j] = p.up[r * nseg + segi[j]]; nlow[j] = p.low[r * nseg + segi[j]]; }
+            }
+        if (LET && p.row_div) nrd = p.row_div[r];
+        if (LET && p.row_mul) nrm = p.row_mul[r];
+    }
+    for (; r < p.rows; r += gridDim.x) {
+        float x[CH][8], cup[CH], clow[CH];
+        const float rd = nrd, rm = nrm;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const int64_t c0 = ((int64_t)j * BT + t) * 8;
-            valid[j] = c0 < p.cols;
+            cup[j] = nup[j];
+            clow[j] = nlow[j];
+            if (valid[j]) nxt[j].unpack(x[j]);
+        }
+        const int64_t rn = r + gridDim.x;
+        if (rn < p.rows) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (valid[j]) {
+                    nxt[j].load(wbase + rn * p.cols + c0[j]);
+                    if (lwc) { nup[j] = p.up[rn * nseg + segi[j]]; nlow[j] = p.low[rn * nseg + segi[j]]; }
+                }
+            if (LET && p.row_div) nrd = p.row_div[rn];
+            if (LET && p.row_mul) nrm = p.row_mul[rn];
+        }
+        float dot = 0.f;
+        const float inv_rd = 1.f / rd;
+        if constexpr (LET) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
             if (valid[j]) {
-                Vec8<TIN>::load(wbase + r * p.cols + c0, x[j]);
                 if (p.shift) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) dot += x[j][i] * p.shift[c0 + i];
+                    for (int i = 0; i < 8; ++i) dot += x[j][i] * shv[j][i];
                 }
                 if (p.col_mul) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) x[j][i] = x[j][i] * p.col_mul[c0 + i];
+                    for (int i = 0; i < 8; ++i) x[j][i] = x[j][i] * cmv[j][i];
                 }
                 if (p.row_div) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) x[j][i] = x[j][i] / rd;
+                    for (int i = 0; i < 8; ++i) x[j][i] = div_nr(x[j][i], rd, inv_rd);
                 }
                 if (p.row_mul) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) x[j][i] = x[j][i] * rm;
                 }
             }
+        }
         }
         // ---- min / max (NaN-propagating like torch.amax/amin) ---------------------------------
         float hi[CH], lo[CH], bad[CH];
@@ -176,19 +252,30 @@ __global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_fwd_kernel(FQ p) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (!valid[j]) continue;
-            const int64_t c0 = ((int64_t)j * BT + t) * 8;
-            const int64_t sidx = r * nseg + (int64_t)((uint32_t)c0 / (uint32_t)p.seg);
+            const int64_t sidx = r * nseg + segi[j];
             float h = hi[j], l = lo[j];
             if (bad[j] != 0.f) { h = NAN; l = NAN; }
-            const QP q = make_qp(h, l, p.up, p.low, sidx, p.nbits, p.symmetric);
+            const QP q = make_qp(h, l, lwc, cup[j], clow[j], p.nbits, p.symmetric);
             float yv[8];
+            const float inv_s = 1.f / q.s;
+            if (q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad[j] == 0.f) {
+                // regular segment (finite non-zero scale, no NaN): no special values can appear below
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v = rne_ste(x[j][i] / q.s) + q.z;
-                v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
-                yv[i] = (v - q.z) * q.s;
+                for (int i = 0; i < 8; ++i) {
+                    float tq;
+                    const float v = fminf(fmaxf(rne_div(x[j][i], q.s, inv_s, &tq) + q.z, 0.f), Q);
+                    yv[i] = (v - q.z) * q.s;
+                }
+            } else {
+                // degenerate segment (constant row -> scale 0, inf/NaN inputs): replay the reference's op sequence
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = rne_ste(x[j][i] / q.s) + q.z;
+                    v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
+                    yv[i] = (v - q.z) * q.s;
+                }
             }
-            Vec8<TOUT>::store(ybase + r * p.cols + c0, yv);
+            Vec8<TOUT>::store(ybase + r * p.cols + c0[j], yv);
             const bool leader = small ? ((t & (lps - 1)) == 0) : (t == 0 && j == 0);
             if (leader) {
                 if (p.scale) p.scale[sidx] = q.s;
@@ -197,7 +284,7 @@ __global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_fwd_kernel(FQ p) {
                 if (p.xmax) p.xmax[sidx] = h;
             }
         }
-        if (p.wshift) {
+        if (LET && p.wshift) {
             float v[1] = {dot};
             const int op[1] = {0};
             block_reduce<1>(v, op, red);
@@ -210,7 +297,7 @@ __global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_fwd_kernel(FQ p) {
 // backward
 // ---------------------------------------------------------------------------------------------------
 template <typename TIN, typename TG, bool LET, int CH>
-__global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_bwd_kernel(FQ p) {
+__global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
     __shared__ float red[3 * 16];
     const int t = threadIdx.x, BT = blockDim.x;
     const bool small = p.seg <= 512;
@@ -225,32 +312,78 @@ __global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_bwd_kernel(FQ p) {
     const bool need_sh = LET && p.g_shift;
 
     constexpr int NACC = LET ? CH : 1;
-    float acc_cm[NACC][8], acc_sh[NACC][8];
+    float acc_cm[NACC][8], acc_sh[NACC][8], cmv[NACC][8];
 #pragma unroll
     for (int j = 0; j < NACC; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { acc_cm[j][i] = 0.f; acc_sh[j][i] = 0.f; }
-
-    for (int64_t r = blockIdx.x; r < p.rows; r += gridDim.x) {
-        float w[CH][8], x[CH][8], G[CH][8];
-        bool valid[CH];
-        const float rd = p.row_div ? p.row_div[r] : 1.f;
-        const float rm = p.row_mul ? p.row_mul[r] : 1.f;
-        const float inv_rd = 1.f / rd;      // gradient path only: reciprocal multiplies instead of IEEE divides
-        const float gws = p.g_wshift ? p.g_wshift[r] : 0.f;
+        for (int i = 0; i < 8; ++i) { acc_cm[j][i] = 0.f; acc_sh[j][i] = 0.f; cmv[j][i] = 1.f; }
+    bool valid[CH];
+    int c0[CH], segi[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        c0[j] = (j * BT + t) * 8;
+        valid[j] = c0[j] < p.cols;
+        segi[j] = (int)((uint32_t)c0[j] / (uint32_t)p.seg);
+        if constexpr (LET) {
+            if (valid[j] && p.col_mul) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) cmv[j][i] = p.col_mul[c0[j] + i];
+            }
+        }
+    }
+    Raw8<TIN> nw[CH];
+    Raw8<TG> ng[CH];
+    float nup[CH], nlow[CH], nrd = 1.f, nrm = 1.f, ngws = 0.f;
+    const bool lwc = p.up != nullptr;
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { nup[j] = 0.f; nlow[j] = 0.f; }
+    int64_t r = blockIdx.x;
+    if (r < p.rows) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (valid[j]) {
+                nw[j].load(wbase + r * p.cols + c0[j]);
+                ng[j].load(gbase + r * p.cols + c0[j]);
+                if (lwc) { nup[j] = p.up[r * nseg + segi[j]]; nlow[j] = p.low[r * nseg + segi[j]]; }
+            }
+        if (LET && p.row_div) nrd = p.row_div[r];
+        if (LET && p.row_mul) nrm = p.row_mul[r];
+        if (LET && p.g_wshift) ngws = p.g_wshift[r];
+    }
+    for (; r < p.rows; r += gridDim.x) {
+        float w[CH][8], x[CH][8], G[CH][8], cup[CH], clow[CH];
+        const float rd = nrd, rm = nrm, gws = ngws;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const int64_t c0 = ((int64_t)j * BT + t) * 8;
-            valid[j] = c0 < p.cols;
+            cup[j] = nup[j];
+            clow[j] = nlow[j];
+            if (valid[j]) { nw[j].unpack(w[j]); ng[j].unpack(G[j]); }
+        }
+        const int64_t rn = r + gridDim.x;
+        if (rn < p.rows) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (valid[j]) {
+                    nw[j].load(wbase + rn * p.cols + c0[j]);
+                    ng[j].load(gbase + rn * p.cols + c0[j]);
+                    if (lwc) { nup[j] = p.up[rn * nseg + segi[j]]; nlow[j] = p.low[rn * nseg + segi[j]]; }
+                }
+            if (LET && p.row_div) nrd = p.row_div[rn];
+            if (LET && p.row_mul) nrm = p.row_mul[rn];
+            if (LET && p.g_wshift) ngws = p.g_wshift[rn];
+        }
+        const float inv_rd = 1.f / rd;      // gradient path only: reciprocal multiplies instead of IEEE divides
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
             if (valid[j]) {
-                Vec8<TIN>::load(wbase + r * p.cols + c0, w[j]);
-                Vec8<TG>::load(gbase + r * p.cols + c0, G[j]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float v = w[j][i];
-                    if (p.col_mul) v = v * p.col_mul[c0 + i];
-                    if (p.row_div) v = v / rd;        // keep the IEEE divide: x must equal the forward's x bit for bit
-                    if (p.row_mul) v = v * rm;        // (ties with hi/lo and the clip mask depend on it)
+                    if constexpr (LET) {
+                        if (p.col_mul) v = v * cmv[j][i];
+                        if (p.row_div) v = div_nr(v, rd, inv_rd);   // same function as the forward: x is bit-identical
+                        if (p.row_mul) v = v * rm;                  // (ties with hi/lo and the clip mask depend on it)
+                    }
                     x[j][i] = v;
                 }
             }
@@ -282,10 +415,9 @@ __global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_bwd_kernel(FQ p) {
         float gs[CH], nhi[CH], nlo[CH], inv_s[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            gs[j] = 0.f; nhi[j] = 0.f; nlo[j] = 0.f;
+            gs[j] = 0.f; nhi[j] = 0.f; nlo[j] = 0.f; inv_s[j] = 0.f;
             if (valid[j]) {
-                const int64_t c0 = ((int64_t)j * BT + t) * 8;
-                qp[j] = make_qp(hi[j], lo[j], p.up, p.low, r * nseg + (int64_t)((uint32_t)c0 / (uint32_t)p.seg), p.nbits, p.symmetric);
+                qp[j] = make_qp(hi[j], lo[j], lwc, cup[j], clow[j], p.nbits, p.symmetric);
                 inv_s[j] = 1.f / qp[j].s;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -320,8 +452,7 @@ __global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_bwd_kernel(FQ p) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (!valid[j]) continue;
-            const int64_t c0 = ((int64_t)j * BT + t) * 8;
-            const int64_t sidx = r * nseg + (int64_t)((uint32_t)c0 / (uint32_t)p.seg);
+            const int64_t sidx = r * nseg + segi[j];
             const QP q = qp[j];
             float ds_dhs, ds_dls;   // d scale / d hi', d scale / d lo'
             if (p.symmetric) {
@@ -359,30 +490,30 @@ __global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_bwd_kernel(FQ p) {
                     if (x[j][i] == q.lo) gv += tie_lo;
                     gxv[i] = gv;
                     if constexpr (LET) {
-                      if (need_let) {
-                        // x = ((w*cm)/rd)*rm ; b = (w*cm)/rd
-                        float a = w[j][i];
-                        if (p.col_mul) a = a * p.col_mul[c0 + i];
-                        const float b = p.row_div ? a * inv_rd : a;
-                        acc_rm += gv * b;
-                        const float gb = p.row_mul ? gv * rm : gv;
-                        acc_rd += gb * (-b * inv_rd);
-                        const float ga = p.row_div ? gb * inv_rd : gb;
-                        acc_cm[j][i] += ga * w[j][i];
-                      }
-                      if (need_sh) acc_sh[j][i] += gws * w[j][i];
+                        if (need_let) {
+                            // x = ((w*cm)/rd)*rm ; b = (w*cm)/rd
+                            const float a = w[j][i] * cmv[j][i];
+                            const float b = a * inv_rd;
+                            acc_rm += gv * b;
+                            const float gb = gv * rm;
+                            acc_rd += gb * (-b * inv_rd);
+                            acc_cm[j][i] += (gb * inv_rd) * w[j][i];
+                        }
+                        if (need_sh) acc_sh[j][i] += gws * w[j][i];
                     }
                 }
-                if (p.gx) Vec8<TG>::store(gxbase + r * p.cols + c0, gxv);
+                if (p.gx) Vec8<TG>::store(gxbase + r * p.cols + c0[j], gxv);
             }
         }
-        if (p.g_row_div || p.g_row_mul) {
-            float v[2] = {acc_rd, acc_rm};
-            const int op[2] = {0, 0};
-            block_reduce<2>(v, op, red);
-            if (t == 0) {
-                if (p.g_row_div) p.g_row_div[r] = v[0];
-                if (p.g_row_mul) p.g_row_mul[r] = v[1];
+        if constexpr (LET) {
+            if (p.g_row_div || p.g_row_mul) {
+                float v[2] = {acc_rd, acc_rm};
+                const int op[2] = {0, 0};
+                block_reduce<2>(v, op, red);
+                if (t == 0) {
+                    if (p.g_row_div) p.g_row_div[r] = v[0];
+                    if (p.g_row_mul) p.g_row_mul[r] = v[1];
+                }
             }
         }
     }
@@ -393,10 +524,9 @@ __global__ void __launch_bounds__(CH == 1 ? 1024 : 512) fq_bwd_kernel(FQ p) {
         float* wsh = p.ws + ((int64_t)gridDim.x + blockIdx.x) * p.cols;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const int64_t c0 = ((int64_t)j * BT + t) * 8;
-            if (c0 < p.cols) {
-                if (p.g_col_mul) Vec8<float>::store(wcm + c0, acc_cm[j]);
-                if (p.g_shift) Vec8<float>::store(wsh + c0, acc_sh[j]);
+            if (valid[j]) {
+                if (p.g_col_mul) Vec8<float>::store(wcm + c0[j], acc_cm[j]);
+                if (p.g_shift) Vec8<float>::store(wsh + c0[j], acc_sh[j]);
             }
         }
       }
@@ -436,9 +566,20 @@ __global__ void __launch_bounds__(256) colreduce_kernel(const float* part, int n
 
 // chunks per thread (1, 4 or 8) and threads per workgroup for a row of `cols` elements: as many waves as the row
 // allows (one 16-byte chunk per lane) before giving a lane more than one chunk.
-void row_geometry(int64_t cols, int* ch, int* bt) {
+int64_t dbg_env(const char* name, int64_t dflt) {
+    const char* v = getenv(name);
+    return v ? atoll(v) : dflt;
+}
+
+// Chunks per thread (1/2/4/8) and threads per workgroup for a row of `cols` elements.  Per-row work that every WAVE
+// repeats (LWC sigmoids, scale/zero-point arithmetic, reductions, barriers) is amortised over chunks-per-thread, so
+// the fewest waves whose registers still fit win: `pref` is the kernel kind's sweet spot (measured), widened only
+// when a row needs more than 512 threads and narrowed for short rows.
+void row_geometry(int64_t cols, int pref, int* ch, int* bt) {
     const int64_t lanes = (cols + 7) / 8;
-    int c = lanes <= 1024 ? 1 : (lanes <= 2048 ? 4 : 8);     // CH=1: <=1024 threads; CH=4/8: <=512 threads
+    int c = (int)dbg_env("OQ_DBG_FQ_CH", pref);
+    while (c > 1 && lanes < 64 * (int64_t)c) c >>= 1;        // short rows: keep one full wave busy
+    while (c < 8 && lanes > 512 * (int64_t)c) c <<= 1;       // long rows: at most 512 threads
     int64_t t = (lanes + c - 1) / c;
     t = ((t + 63) / 64) * 64;
     *ch = c;
@@ -458,17 +599,26 @@ int check_shape(const char* fn, int64_t rows, int64_t cols, int64_t seg, int nbi
     } else {
         OQ_CHECK_ARG(seg == cols, "%s: seg %lld > 512 must equal cols %lld", fn, (long long)seg, (long long)cols);
     }
-    OQ_CHECK_ARG(cols <= 8 * 1024 * 4, "%s: cols %lld exceeds %d", fn, (long long)cols, 8 * 1024 * 4);
+    OQ_CHECK_ARG(cols <= 8 * 512 * 8, "%s: cols %lld exceeds %d", fn, (long long)cols, 8 * 512 * 8);
     return OQ_OK;
 }
 
 }  // namespace
 
-#define FQ_DISPATCH_FWD(TIN, TOUT)                                                                              \
-    do {                                                                                                        \
-        if (ch == 1) hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, 1>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);      \
-        else if (ch == 4) hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, 4>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p); \
-        else hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, 8>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);              \
+#define FQ_LAUNCH_FWD(TIN, TOUT, L, C_) hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, L, C_>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p)
+#define FQ_DISPATCH_FWD(TIN, TOUT)                                     \
+    do {                                                               \
+        if (let) {                                                     \
+            if (ch == 1) FQ_LAUNCH_FWD(TIN, TOUT, true, 1);            \
+            else if (ch == 2) FQ_LAUNCH_FWD(TIN, TOUT, true, 2);       \
+            else if (ch == 4) FQ_LAUNCH_FWD(TIN, TOUT, true, 4);       \
+            else FQ_LAUNCH_FWD(TIN, TOUT, true, 8);                    \
+        } else {                                                       \
+            if (ch == 1) FQ_LAUNCH_FWD(TIN, TOUT, false, 1);           \
+            else if (ch == 2) FQ_LAUNCH_FWD(TIN, TOUT, false, 2);      \
+            else if (ch == 4) FQ_LAUNCH_FWD(TIN, TOUT, false, 4);      \
+            else FQ_LAUNCH_FWD(TIN, TOUT, false, 8);                   \
+        }                                                              \
     } while (0)
 
 extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits,
@@ -485,9 +635,11 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     p.w = w; p.rows = rows; p.cols = cols; p.seg = seg; p.nbits = nbits; p.symmetric = symmetric;
     p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = wshift ? shift : nullptr;
     p.up = up; p.low = low; p.y = y; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax; p.wshift = wshift;
+    const bool let = col_mul || row_div || row_mul || shift;
     int ch, bt;
-    row_geometry(cols, &ch, &bt);
-    const int64_t grid = rows < 8192 ? rows : 8192;
+    row_geometry(cols, 2, &ch, &bt);
+    const int64_t gcap = dbg_env("OQ_DBG_FQ_BLOCKS", OQ_FQ_MAX_BLOCKS);
+    const int64_t grid = rows < gcap ? rows : gcap;
     const int key = w_dtype * 3 + y_dtype;
     switch (key) {
         case OQ_F32 * 3 + OQ_F32: FQ_DISPATCH_FWD(float, float); break;
@@ -508,10 +660,12 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     do {                                                             \
         if (let) {                                                   \
             if (ch == 1) FQ_LAUNCH_BWD(TIN, TG, true, 1);            \
+            else if (ch == 2) FQ_LAUNCH_BWD(TIN, TG, true, 2);       \
             else if (ch == 4) FQ_LAUNCH_BWD(TIN, TG, true, 4);       \
             else FQ_LAUNCH_BWD(TIN, TG, true, 8);                    \
         } else {                                                     \
             if (ch == 1) FQ_LAUNCH_BWD(TIN, TG, false, 1);           \
+            else if (ch == 2) FQ_LAUNCH_BWD(TIN, TG, false, 2);      \
             else if (ch == 4) FQ_LAUNCH_BWD(TIN, TG, false, 4);      \
             else FQ_LAUNCH_BWD(TIN, TG, false, 8);                   \
         }                                                            \
@@ -538,17 +692,18 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
     p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = shift; p.up = up; p.low = low;
     p.g = g; p.g_wshift = g_wshift; p.g_up = g_up; p.g_low = g_low; p.gx = gx;
     p.g_col_mul = g_col_mul; p.g_shift = g_shift; p.g_row_div = g_row_div; p.g_row_mul = g_row_mul;
+    // the LET instantiation is needed whenever the transform is present (x must be recomputed), not only for its grads
+    const bool let = col_mul || row_div || row_mul || g_col_mul || g_shift || g_row_div || g_row_mul;
     int ch, bt;
-    row_geometry(cols, &ch, &bt);
+    row_geometry(cols, 2, &ch, &bt);
     // column accumulators are flushed once per workgroup: keep the grid small when they are live
-    const int64_t cap = (g_col_mul || g_shift) ? OQ_FQ_BWD_MAX_BLOCKS : 8192;
+    const int64_t cap = (g_col_mul || g_shift) ? OQ_FQ_BWD_MAX_BLOCKS : dbg_env("OQ_DBG_FQ_BLOCKS", OQ_FQ_MAX_BLOCKS);
     const int64_t grid = rows < cap ? rows : cap;
     if (g_col_mul || g_shift) {
         OQ_CHECK_ARG(workspace && workspace_floats >= 2 * grid * cols,
                      "oq_fakequant_bwd: workspace of %lld floats needed (oq_fakequant_bwd_workspace)", (long long)(2 * grid * cols));
         p.ws = workspace;
     }
-    const bool let = g_col_mul || g_shift || g_row_div || g_row_mul;
     const int key = w_dtype * 3 + g_dtype;
     switch (key) {
         case OQ_F32 * 3 + OQ_F32: FQ_DISPATCH_BWD(float, float); break;
