@@ -18,6 +18,7 @@
 //     output columns: the epilogue stores 8/16 B per lane with no shuffles.
 // f32 path (parity mode): exact f32 on v_mfma_f32_16x16x4_f32, 64x64x16 tile, scalar predicated loads: any
 // shape, any alignment; numerics = k-ordered fmaf chain.
+#include <stdlib.h>
 #include "oq_common.h"
 
 namespace {
@@ -234,6 +235,257 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 256x128x64 kernel: 8 waves (4x2, 64x64 per wave), LDS-DMA staging (global_load_lds, 16 B per lane), 3-stage LDS
+// ring (3 x 48 KiB) with a COUNTED vmcnt so one K-tile stays in flight across the single barrier per K-step.
+// No registers or ds_write are spent on staging; swizzles are applied on the per-lane SOURCE address because the
+// LDS-DMA destination is lane-linear (wave-uniform base + lane*16).
+// ---------------------------------------------------------------------------------------------------
+constexpr int P3_BM = 256, P3_BN = 128;
+constexpr int P3_A_BYTES = P3_BM * BK * 2;   // 32 KiB
+constexpr int P3_B_BYTES = P3_BN * BK * 2;   // 16 KiB
+constexpr int P3_STAGE = P3_A_BYTES + P3_B_BYTES;
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+__device__ __forceinline__ void glds16(const bf16_t* src, char* dst) {
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+}
+
+// per-lane source pointer of LDS-DMA piece `piece` (1 KiB of the operand tile) at k0 = 0.
+//   KC: piece = 8 rows x 128 B.   KS: piece = (1024 / ROWB) k-rows of ROWB bytes (ROWB = 2 * tile rows).
+template <bool KC, int ROWB>
+__device__ __forceinline__ const bf16_t* piece_src(const bf16_t* base, int64_t ld, int64_t i0, int64_t I, int piece,
+                                                   int lane) {
+    if (KC) {
+        const int row = piece * 8 + (lane >> 3);
+        const int src_chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int64_t i = i0 + row;
+        i = i < I ? i : I - 1;
+        return base + i * ld + src_chunk * 8;
+    } else {
+        constexpr int LPR = ROWB / 16;              // lanes (16-B chunks) per k-row
+        const int krow = piece * (64 / LPR) + lane / LPR;
+        const int pc16 = lane % LPR;
+        const int c32 = (pc16 >> 1) ^ kstr_f(krow);
+        int64_t i = i0 + (c32 * 2 + (pc16 & 1)) * 8;
+        i = i < I ? i : I - 8;
+        return base + (int64_t)krow * ld + i;
+    }
+}
+
+template <bool KC, int ROWB>
+__device__ __forceinline__ bf16x8 read_frag3(const char* lds, int row0, int ks, int lane) {
+    if (KC) {
+        const int row = row0 + (lane & 15);
+        const int chunk = ks * 4 + (lane >> 4);
+        const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+        return *reinterpret_cast<const bf16x8*>(lds + off);
+    } else {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int k = ks * 32 + 8 * g + q;
+        const int c32 = row0 >> 4;
+        const int off0 = k * ROWB + ((c32 ^ kstr_f(k)) << 5) + pp * 8;
+        const int off1 = (k + 4) * ROWB + ((c32 ^ kstr_f(k + 4)) << 5) + pp * 8;
+        typedef __attribute__((address_space(3))) s16x4 lds_s4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + off0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + off1));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+// ---- fragment reads as inline asm --------------------------------------------------------------------------
+// hipcc puts an `s_waitcnt vmcnt(0)` in front of every compiler-visible ds_read_b64_tr_b16 while an LDS-DMA is in
+// flight (it cannot prove the transposed read does not alias the DMA destination), which drains the prefetched
+// K-tile each iteration (measured: -25 % on every layout with a k-strided operand).  Reads issued from inline asm
+// are invisible to that pass; their completion is waited for explicitly (counted lgkmcnt) and a sched_barrier keeps
+// the MFMAs below the wait (cdna guide 5.4 rule 18).
+template <int OFF>
+__device__ __forceinline__ bf16x8 asm_ds_read_b128(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ s16x4 asm_ds_read_tr(uint32_t addr) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+    return v;
+}
+
+// Per-lane LDS byte offsets (relative to the stage's operand base) of the fragment reads of one wave.
+//   KC: base[ks]  (+ i*2048 immediate per 16-row tile i)       -> base[0..1]
+//   KS: base[i]   (+ ks*32*ROWB and +4*ROWB immediates)         -> base[0..3]
+template <bool KC, int ROWB>
+__device__ __forceinline__ void frag_bases(int wave_row0, int lane, uint32_t (&base)[4]) {
+    if (KC) {
+        const int r = lane & 15;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            base[ks] = (uint32_t)((wave_row0 + r) * 128 + ((((ks * 4) + (lane >> 4)) ^ (r >> 1)) << 4));
+        base[2] = base[3] = 0;
+    } else {
+        const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+        const int k = 8 * g + q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c32 = (wave_row0 >> 4) + i;
+            base[i] = (uint32_t)(k * ROWB + ((c32 ^ kstr_f(k)) << 5) + pp * 8);
+        }
+    }
+}
+
+template <bool KC, int ROWB, int KS_, int I_>
+__device__ __forceinline__ bf16x8 frag_read(const uint32_t (&b)[4], uint32_t stage_off) {
+    if constexpr (KC) {
+        return asm_ds_read_b128<I_ * 2048>(b[KS_] + stage_off);
+    } else {
+        const s16x4 lo = asm_ds_read_tr<KS_ * 32 * ROWB>(b[I_] + stage_off);
+        const s16x4 hi = asm_ds_read_tr<KS_ * 32 * ROWB + 4 * ROWB>(b[I_] + stage_off);
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool AKC, bool BKC, typename TOUT>
+__global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * P3_STAGE];   // ONE array: see cdna guide (second-object trap)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    int tile;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    int64_t m0, n0;
+    if (p.nmajor) { n0 = (int64_t)(tile / p.tiles_m) * P3_BN; m0 = (int64_t)(tile % p.tiles_m) * P3_BM; }
+    else { m0 = (int64_t)(tile / p.tiles_n) * P3_BM; n0 = (int64_t)(tile % p.tiles_n) * P3_BN; }
+    const int64_t bo = blockIdx.z / p.batch_i, bi = blockIdx.z % p.batch_i;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.a) + bo * p.sa_o + bi * p.sa_i;
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.b) + bo * p.sb_o + bi * p.sb_i;
+    TOUT* C = reinterpret_cast<TOUT*>(p.c) + bo * p.sc_o + bi * p.sc_i;
+
+    // LDS-DMA pieces of this wave: A pieces wid + 8q (q < 4), B pieces wid + 8q (q < 2)
+    const bf16_t* ga[4];
+    const bf16_t* gb[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ga[q] = piece_src<AKC, 2 * P3_BM>(A, p.lda, m0, p.M, wid + 8 * q, lane);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) gb[q] = piece_src<BKC, 2 * P3_BN>(B, p.ldb, n0, p.N, wid + 8 * q, lane);
+    const int64_t astep = AKC ? BK : (int64_t)BK * p.lda;
+    const int64_t bstep = BKC ? BK : (int64_t)BK * p.ldb;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t ba[4], bb[4];
+    frag_bases<AKC, 2 * P3_BM>(wm * 64, lane, ba);
+    frag_bases<BKC, 2 * P3_BN>(wn * 64, lane, bb);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+
+    const int nt = (int)(p.K / BK);
+    auto issue = [&](int stage) {
+        char* sa = smem + stage * P3_STAGE + wid * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { glds16(ga[q], sa + q * 8192); ga[q] += astep; }
+        char* sb = sa + P3_A_BYTES;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { glds16(gb[q], sb + q * 8192); gb[q] += bstep; }
+    };
+    issue(0);
+    if (nt > 1) {
+        issue(1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int s_cur = 0, s_pre = 2;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 2 < nt) issue(s_pre);
+        // all fragment reads of the K-tile are issued up front (asm, see above); k-substep 1's reads land under the
+        // MFMAs of k-substep 0 behind a counted lgkmcnt
+        const uint32_t sao = lds_base + (uint32_t)(s_cur * P3_STAGE);
+        const uint32_t sbo = sao + P3_A_BYTES;
+        bf16x8 fa[2][4], fb[2][4];
+        fa[0][0] = frag_read<AKC, 2 * P3_BM, 0, 0>(ba, sao);
+        fa[0][1] = frag_read<AKC, 2 * P3_BM, 0, 1>(ba, sao);
+        fa[0][2] = frag_read<AKC, 2 * P3_BM, 0, 2>(ba, sao);
+        fa[0][3] = frag_read<AKC, 2 * P3_BM, 0, 3>(ba, sao);
+        fb[0][0] = frag_read<BKC, 2 * P3_BN, 0, 0>(bb, sbo);
+        fb[0][1] = frag_read<BKC, 2 * P3_BN, 0, 1>(bb, sbo);
+        fb[0][2] = frag_read<BKC, 2 * P3_BN, 0, 2>(bb, sbo);
+        fb[0][3] = frag_read<BKC, 2 * P3_BN, 0, 3>(bb, sbo);
+        fa[1][0] = frag_read<AKC, 2 * P3_BM, 1, 0>(ba, sao);
+        fa[1][1] = frag_read<AKC, 2 * P3_BM, 1, 1>(ba, sao);
+        fa[1][2] = frag_read<AKC, 2 * P3_BM, 1, 2>(ba, sao);
+        fa[1][3] = frag_read<AKC, 2 * P3_BM, 1, 3>(ba, sao);
+        fb[1][0] = frag_read<BKC, 2 * P3_BN, 1, 0>(bb, sbo);
+        fb[1][1] = frag_read<BKC, 2 * P3_BN, 1, 1>(bb, sbo);
+        fb[1][2] = frag_read<BKC, 2 * P3_BN, 1, 2>(bb, sbo);
+        fb[1][3] = frag_read<BKC, 2 * P3_BN, 1, 3>(bb, sbo);
+        // LDS ops complete in order: "at most N1 outstanding" (N1 = reads of k-substep 1, capped at the 4-bit counter's
+        // 15) implies every read of k-substep 0 has landed
+        constexpr int N1 = ((AKC ? 4 : 8) + (BKC ? 4 : 8)) > 15 ? 15 : ((AKC ? 4 : 8) + (BKC ? 4 : 8));
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N1));
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);     // keep k-substep 0's MFMAs ABOVE the second wait
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (t + 1 < nt) {
+            // tile t+1 (issued one iteration ago) must have landed; tile t+2 (just issued) stays in flight
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        s_cur = s_cur == 2 ? 0 : s_cur + 1;
+        s_pre = s_pre == 2 ? 0 : s_pre + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r] * p.alpha;
+                if (p.bias) v[r] += p.bias[n + r];
+            }
+            TOUT* dst = C + m * p.ldc + n;
+            if constexpr (sizeof(TOUT) == 4) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+                *reinterpret_cast<bf4*>(dst) = bf4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // exact f32 path
 // ---------------------------------------------------------------------------------------------------
 constexpr int FM = 64, FN = 64, FK = 16;
@@ -349,6 +601,26 @@ extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias
         else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T, false>), grid, dim3(256), 0, st, p);      \
     } while (0)
         const int key = (a_kc ? 4 : 0) | (b_kc ? 2 : 0) | (out_dtype == OQ_F32 ? 1 : 0);
+        static const int use_p3 = getenv("OQ_GEMM_NO_P3") ? 0 : 1;
+        if (use_p3 && fast && M >= 128 && N >= 128) {
+            const int64_t tm3 = (M + P3_BM - 1) / P3_BM, tn3 = (N + P3_BN - 1) / P3_BN;
+            p.tiles_n = (int)tn3;
+            p.tiles_m = (int)tm3;
+            dim3 grid3((unsigned)(tm3 * tn3), 1, (unsigned)(batch_o * batch_i));
+#define LAUNCH_P3(AK, BK_, T) hipLaunchKernelGGL((gemm_bf16_p3_kernel<AK, BK_, T>), grid3, dim3(512), 0, st, p)
+            switch (key) {
+                case 0: LAUNCH_P3(false, false, bf16_t); break;
+                case 1: LAUNCH_P3(false, false, float); break;
+                case 2: LAUNCH_P3(false, true, bf16_t); break;
+                case 3: LAUNCH_P3(false, true, float); break;
+                case 4: LAUNCH_P3(true, false, bf16_t); break;
+                case 5: LAUNCH_P3(true, false, float); break;
+                case 6: LAUNCH_P3(true, true, bf16_t); break;
+                case 7: LAUNCH_P3(true, true, float); break;
+            }
+            OQ_CHECK_LAUNCH("oq_gemm(p3)");
+            return OQ_OK;
+        }
         switch (key) {
             case 0: LAUNCH_BF16(false, false, bf16_t); break;
             case 1: LAUNCH_BF16(false, false, float); break;
