@@ -23,6 +23,11 @@
 
 namespace {
 
+int dbg_env_i(const char* name, int dflt) {     // tuning / A-B switches (read per call so one process can compare)
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 struct GemmP {
     const void* a;
     const void* b;
@@ -348,7 +353,7 @@ __device__ __forceinline__ bf16x8 frag_read(const uint32_t (&b)[4], uint32_t sta
     }
 }
 
-template <bool AKC, bool BKC, typename TOUT>
+template <bool AKC, bool BKC, typename TOUT, bool STAGGER, bool SPLIT>
 __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[3 * P3_STAGE];   // ONE array: see cdna guide (second-object trap)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -397,6 +402,28 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) { glds16(gb[q], sb + q * 8192); gb[q] += bstep; }
     };
+    // ---- staggered two-group schedule ----------------------------------------------------------------------
+    // Waves w and w+4 share a SIMD.  Each K-tile is split into a load half H1 (issue the LDS-DMA of tile t+2, read
+    // tile t's fragments into registers) and a pure-MFMA half H2, separated by barriers; group B (waves 4-7) runs
+    // one barrier interval behind group A, so on every SIMD one wave issues MFMAs while its partner issues
+    // LDS-DMA / ds_reads.  Hazards (cdna guide: "one barrier MORE when two wave groups run staggered"):
+    //   RAW  tile t is read in H1(t) (interval 2t for A, 2t+1 for B); every wave waits `vmcnt` for its own pieces of
+    //        tile t at the end of its H1(t-1) and then passes a barrier (<= interval 2t-1 | 2t).
+    //   WAR  the DMA of tile t+2 overwrites tile t-1's stage; all fragment reads of tile t-1 are COMPLETE
+    //        (lgkmcnt(0)) before the barrier that ends H1(t-1) of either group (<= interval 2t-1 | 2t).
+    const bool grp_b = STAGGER && wid >= 4;
+    // SPLIT: the 6 LDS-DMA pieces of a tile are issued half in H1 and half between the MFMAs of H2, which shortens the
+    // load half (the longer of the two) of every interval
+    auto issue_h1 = [&](int stage) {
+        char* sa = smem + stage * P3_STAGE + wid * 1024;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { glds16(ga[q], sa + q * 8192); ga[q] += astep; }
+    };
+    auto issue_h2 = [&](int stage, int which) {
+        char* sa = smem + stage * P3_STAGE + wid * 1024;
+        if (which == 0) { glds16(ga[3], sa + 3 * 8192); ga[3] += astep; }
+        else { glds16(gb[which - 1], sa + P3_A_BYTES + (which - 1) * 8192); gb[which - 1] += bstep; }
+    };
     issue(0);
     if (nt > 1) {
         issue(1);
@@ -406,11 +433,14 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (grp_b) __builtin_amdgcn_s_barrier();      // group B idles through interval 0
     int s_cur = 0, s_pre = 2;
     for (int t = 0; t < nt; ++t) {
-        if (t + 2 < nt) issue(s_pre);
-        // all fragment reads of the K-tile are issued up front (asm, see above); k-substep 1's reads land under the
-        // MFMAs of k-substep 0 behind a counted lgkmcnt
+        // ---------------- H1(t) ----------------
+        if (t + 2 < nt) {
+            if (SPLIT) issue_h1(s_pre);
+            else issue(s_pre);
+        }
         const uint32_t sao = lds_base + (uint32_t)(s_cur * P3_STAGE);
         const uint32_t sbo = sao + P3_A_BYTES;
         bf16x8 fa[2][4], fb[2][4];
@@ -430,36 +460,53 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
         fb[1][1] = frag_read<BKC, 2 * P3_BN, 1, 1>(bb, sbo);
         fb[1][2] = frag_read<BKC, 2 * P3_BN, 1, 2>(bb, sbo);
         fb[1][3] = frag_read<BKC, 2 * P3_BN, 1, 3>(bb, sbo);
-        // LDS ops complete in order: "at most N1 outstanding" (N1 = reads of k-substep 1, capped at the 4-bit counter's
-        // 15) implies every read of k-substep 0 has landed
-        constexpr int N1 = ((AKC ? 4 : 8) + (BKC ? 4 : 8)) > 15 ? 15 : ((AKC ? 4 : 8) + (BKC ? 4 : 8));
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(N1));
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[0][j], fa[0][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);     // keep k-substep 0's MFMAs ABOVE the second wait
-        asm volatile("s_waitcnt lgkmcnt(0)");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[1][j], fa[1][i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
         if (t + 1 < nt) {
-            // tile t+1 (issued one iteration ago) must have landed; tile t+2 (just issued) stays in flight
-            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            // my pieces of tile t+1 (issued one H1 ago) have landed; tile t+2 (just issued) stays in flight
+            if (t + 2 < nt) {
+                if (SPLIT) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)");      // fragments are in registers: the stage may be overwritten
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---------------- H2(t): 32 MFMAs on registers ----------------
+        __builtin_amdgcn_s_setprio(1);
+        if (SPLIT) {
+            const bool more = t + 2 < nt;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+                    // one DMA piece after MFMA groups 2, 4 and 6 (of 8)
+                    if (more && ks * 4 + i == 1) issue_h2(s_pre, 0);
+                    if (more && ks * 4 + i == 3) issue_h2(s_pre, 1);
+                    if (more && ks * 4 + i == 5) issue_h2(s_pre, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         s_cur = s_cur == 2 ? 0 : s_cur + 1;
         s_pre = s_pre == 2 ? 0 : s_pre + 1;
     }
+    if (STAGGER && !grp_b) __builtin_amdgcn_s_barrier();     // group A's matching extra barrier
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -601,13 +648,20 @@ extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias
         else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T, false>), grid, dim3(256), 0, st, p);      \
     } while (0)
         const int key = (a_kc ? 4 : 0) | (b_kc ? 2 : 0) | (out_dtype == OQ_F32 ? 1 : 0);
-        static const int use_p3 = getenv("OQ_GEMM_NO_P3") ? 0 : 1;
+        const int use_p3 = dbg_env_i("OQ_GEMM_NO_P3", 0) ? 0 : 1;
         if (use_p3 && fast && M >= 128 && N >= 128) {
             const int64_t tm3 = (M + P3_BM - 1) / P3_BM, tn3 = (N + P3_BN - 1) / P3_BN;
             p.tiles_n = (int)tn3;
             p.tiles_m = (int)tm3;
             dim3 grid3((unsigned)(tm3 * tn3), 1, (unsigned)(batch_o * batch_i));
-#define LAUNCH_P3(AK, BK_, T) hipLaunchKernelGGL((gemm_bf16_p3_kernel<AK, BK_, T>), grid3, dim3(512), 0, st, p)
+            const bool stagger = dbg_env_i("OQ_GEMM_STAGGER", 1) != 0;
+            const bool split = dbg_env_i("OQ_GEMM_SPLIT", 1) != 0;
+#define LAUNCH_P3(AK, BK_, T)                                                                                          \
+    do {                                                                                                               \
+        if (stagger && split) hipLaunchKernelGGL((gemm_bf16_p3_kernel<AK, BK_, T, true, true>), grid3, dim3(512), 0, st, p);  \
+        else if (stagger) hipLaunchKernelGGL((gemm_bf16_p3_kernel<AK, BK_, T, true, false>), grid3, dim3(512), 0, st, p);     \
+        else hipLaunchKernelGGL((gemm_bf16_p3_kernel<AK, BK_, T, false, false>), grid3, dim3(512), 0, st, p);                 \
+    } while (0)
             switch (key) {
                 case 0: LAUNCH_P3(false, false, bf16_t); break;
                 case 1: LAUNCH_P3(false, false, float); break;
