@@ -130,7 +130,12 @@ def cpu_baseline(name, n_steps=1):
     from oracle import ref_cpu as R
     from omniquant_amd import synthetic as S
     arch, wbits, abits, group, lwc, let, let_lr, alpha, aug = CONFIGS[name]
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's job a 16-core CPU share (more threads only oversubscribe the shared host)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     cfg = S.make_config(arch)
     layer = S.make_layer(cfg, seed=0, device="cpu")
