@@ -73,6 +73,11 @@ int64_t oq_fakequant_bwd_workspace(int64_t rows, int64_t cols);
  *   A(b,m,k) = a[bo*sa_o + bi*sa_i + (a_kc ? m*lda + k : k*lda + m)]   (b = bo*batch_i + bi)
  *   B(b,n,k) = bm[bo*sb_o + bi*sb_i + (b_kc ? n*ldb + k : k*ldb + n)]
  *   C        = c[bo*sc_o + bi*sc_i + m*ldc + n]
+ * tri_mode (causal attention; rows/cols/k are token positions of ONE square [T,T] problem per batch):
+ *   0 dense;  1 skip output tiles entirely above the diagonal (n0 >= m0 + tile_m): scores, dP;
+ *   2 contraction restricted to k < m0 + tile_m (P@V, dS@K);  3 contraction restricted to k >= m0 (dS^T@Q, P^T@dO).
+ *   Modes 2/3 rely on the masked part of the [T,T] operand being ZERO inside the diagonal 256-block (what
+ *   oq_softmax_fwd/bwd write with causal=1); everything beyond that block is never read.
  * in_dtype OQ_BF16: bf16 operands on v_mfma_f32_16x16x32_bf16, f32 accumulate.
  * in_dtype OQ_F32 : exact f32 on v_mfma_f32_16x16x4_f32 (parity mode).
  * out_dtype OQ_F32 or OQ_BF16.  Alignment: contiguous dims and leading dims multiples of 8 elements.
@@ -81,7 +86,7 @@ int oq_gemm(const void* a, const void* bm, void* c, const float* bias,
             int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
             int a_kc, int b_kc, int in_dtype, int out_dtype, float alpha,
             int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
-            int64_t sc_o, int64_t sc_i, void* stream);
+            int64_t sc_o, int64_t sc_i, int tri_mode, void* stream);
 
 /* column sums: out[n] = sum_m x[m,n]  (bias gradients).  out f32, zeroed by the callee. */
 int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, float* out, void* stream);
@@ -104,6 +109,8 @@ int64_t oq_norm_bwd_workspace(int64_t rows, int64_t cols);
  *       inverse!=0 applies the transposed rotation (backward).
  * softmax: p = softmax(max(s*alpha + mask[row % mask_rows], lowest)) over the last dim, f32 math.
  *       rows = batch*heads*Tq; mask f32 [mask_rows, cols] or NULL.
+ *       causal != 0 (requires Tq == cols, mask NULL): row t = row % cols attends to columns <= t only; columns
+ *       t+1 .. roundup(t+1,256)-1 are written as 0 and the rest of the row is neither read nor written.
  */
 int oq_rope(const void* x, void* y, int dtype, int64_t T, int64_t heads, int64_t hd, const float* cos, const float* sin,
             int inverse, void* stream);
@@ -113,9 +120,9 @@ int oq_silu_mul_bwd(const void* gate, const void* up, const void* gy, void* ggat
 int oq_relu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream);
 int oq_relu_bwd(const void* x, const void* gy, void* gx, int dtype, int64_t n, void* stream);
 int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols, float alpha, const float* mask,
-                   int64_t mask_rows, void* stream);
+                   int64_t mask_rows, int causal, void* stream);
 int oq_softmax_bwd(const void* p, const void* gp, void* gs, int dtype, int64_t rows, int64_t cols, float alpha,
-                   void* stream);
+                   int causal, void* stream);
 /* loss[0] += mean((out-t1)^2) (+ mean((out-t2)^2) if t2); g = dloss/dout * gscale.  loss zeroed by caller. */
 int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, int dtype, int64_t n, float gscale,
                    float* loss, void* g, void* stream);

@@ -23,7 +23,7 @@ SIGNATURES = {
     "oq_fakequant_bwd": [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                          _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_gemm": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
-                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _vp],
+                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp],
     "oq_norm_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "oq_norm_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
@@ -32,8 +32,8 @@ SIGNATURES = {
     "oq_silu_mul_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
     "oq_relu_fwd": [_vp, _vp, _i32, _i64, _vp],
     "oq_relu_bwd": [_vp, _vp, _vp, _i32, _i64, _vp],
-    "oq_softmax_fwd": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _i64, _vp],
-    "oq_softmax_bwd": [_vp, _vp, _vp, _i32, _i64, _i64, _f32, _vp],
+    "oq_softmax_fwd": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _i64, _i32, _vp],
+    "oq_softmax_bwd": [_vp, _vp, _vp, _i32, _i64, _i64, _f32, _i32, _vp],
     "oq_mse_fwd_bwd": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],
     "oq_add": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_scale": [_vp, _f32, _vp, _i32, _i64, _vp],

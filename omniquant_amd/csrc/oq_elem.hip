@@ -102,7 +102,7 @@ constexpr int SM_CH = 8;   // 8 chunks * 8 elems * 64 lanes = 4096 columns max p
 
 template <typename T>
 __global__ void __launch_bounds__(256) softmax_fwd_kernel(const T* s, T* p, int64_t rows, int64_t cols, float alpha,
-                                                          const float* mask, int64_t mask_rows) {
+                                                          const float* mask, int64_t mask_rows, int causal) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -111,15 +111,23 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(const T* s, T* p, int6
         float v[SM_CH][8];
         float mx = -INFINITY;
         const float* mrow = mask ? mask + (r % mask_rows) * cols : nullptr;
+        // causal: this row attends to columns <= tq; zeros are written up to the end of its 256-column block and
+        // nothing beyond that is read or written (the causal GEMM modes never touch it)
+        // tq is wave-uniform (one row per wave): chunk-level skipping is a scalar branch, lanes beyond the diagonal
+        // inside a live chunk load (valid, possibly unwritten) memory and are masked by a select -> no divergence
+        const int64_t tq = causal ? (int64_t)__builtin_amdgcn_readfirstlane((int)(r % cols)) : cols - 1;
+        const int64_t zend = causal ? (((tq >> 8) + 1) << 8 < cols ? ((tq >> 8) + 1) << 8 : cols) : cols;
+        const int nch = (int)(tq >> 9) + 1;          // 512 columns per wave chunk
 #pragma unroll
         for (int j = 0; j < SM_CH; ++j) {
             const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
-            if (c0 < cols) {
+            if (j < nch && c0 < cols) {
                 Vec8<T>::load(s + r * cols + c0, v[j]);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float z = v[j][i] * alpha;
                     if (mrow) z = fmaxf(z + mrow[c0 + i], lowest);
+                    z = (c0 + i > tq) ? -INFINITY : z;
                     v[j][i] = z;
                     mx = fmaxf(mx, z);
                 }
@@ -130,7 +138,7 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(const T* s, T* p, int6
 #pragma unroll
         for (int j = 0; j < SM_CH; ++j) {
             const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
-            if (c0 < cols) {
+            if (j < nch && c0 < cols) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { v[j][i] = expf(v[j][i] - mx); sum += v[j][i]; }
             }
@@ -140,10 +148,10 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(const T* s, T* p, int6
 #pragma unroll
         for (int j = 0; j < SM_CH; ++j) {
             const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
-            if (c0 < cols) {
+            if (c0 < zend) {
                 float o[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = v[j][i] * inv;
+                for (int i = 0; i < 8; ++i) o[i] = (j < nch) ? v[j][i] * inv : 0.f;    // exp(-inf) = 0 beyond tq
                 Vec8<T>::store(p + r * cols + c0, o);
             }
         }
@@ -152,31 +160,39 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(const T* s, T* p, int6
 
 template <typename T>
 __global__ void __launch_bounds__(256) softmax_bwd_kernel(const T* p, const T* gp, T* gs, int64_t rows, int64_t cols,
-                                                          float alpha) {
+                                                          float alpha, int causal) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r = wave; r < rows; r += nwaves) {
         float pv[SM_CH][8], gv[SM_CH][8];
         float dot = 0.f;
+        const int64_t tq = causal ? (int64_t)__builtin_amdgcn_readfirstlane((int)(r % cols)) : cols - 1;
+        const int64_t zend = causal ? (((tq >> 8) + 1) << 8 < cols ? ((tq >> 8) + 1) << 8 : cols) : cols;
+        const int nch = (int)(tq >> 9) + 1;
 #pragma unroll
         for (int j = 0; j < SM_CH; ++j) {
             const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
-            if (c0 < cols) {
+            if (j < nch && c0 < cols) {
                 Vec8<T>::load(p + r * cols + c0, pv[j]);
                 Vec8<T>::load(gp + r * cols + c0, gv[j]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) dot += pv[j][i] * gv[j][i];
+                for (int i = 0; i < 8; ++i) {
+                    const bool dead = c0 + i > tq;                  // dP beyond the diagonal may be unwritten memory
+                    pv[j][i] = dead ? 0.f : pv[j][i];
+                    gv[j][i] = dead ? 0.f : gv[j][i];
+                    dot += pv[j][i] * gv[j][i];
+                }
             }
         }
         dot = wave_sum(dot);
 #pragma unroll
         for (int j = 0; j < SM_CH; ++j) {
             const int64_t c0 = ((int64_t)j * 64 + lane) * 8;
-            if (c0 < cols) {
+            if (c0 < zend) {
                 float o[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = pv[j][i] * (gv[j][i] - dot) * alpha;
+                for (int i = 0; i < 8; ++i) o[i] = (j < nch) ? pv[j][i] * (gv[j][i] - dot) * alpha : 0.f;
                 Vec8<T>::store(gs + r * cols + c0, o);
             }
         }
@@ -308,26 +324,28 @@ extern "C" int oq_relu_bwd(const void* x, const void* gy, void* gx, int dtype, i
 }
 
 extern "C" int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols, float alpha,
-                              const float* mask, int64_t mask_rows, void* stream) {
+                              const float* mask, int64_t mask_rows, int causal, void* stream) {
+    OQ_CHECK_ARG(!causal || (!mask && rows % cols == 0), "oq_softmax_fwd: causal needs mask == NULL and square [T,T] problems");
     OQ_CHECK_ARG(s && p, "oq_softmax_fwd: null pointer");
     OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 64 * 8 * SM_CH, "oq_softmax_fwd: cols %lld (multiple of 8, <= %d)", (long long)cols, 64 * 8 * SM_CH);
     OQ_CHECK_ARG(!mask || mask_rows > 0, "oq_softmax_fwd: mask_rows");
     const int64_t grid = (rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192;
     hipStream_t st = (hipStream_t)stream;
     DT_SWITCH("oq_softmax_fwd", dtype,
-              hipLaunchKernelGGL((softmax_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)s, (float*)p, rows, cols, alpha, mask, mask_rows),
-              hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)s, (bf16_t*)p, rows, cols, alpha, mask, mask_rows));
+              hipLaunchKernelGGL((softmax_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)s, (float*)p, rows, cols, alpha, mask, mask_rows, causal),
+              hipLaunchKernelGGL((softmax_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)s, (bf16_t*)p, rows, cols, alpha, mask, mask_rows, causal));
 }
 
 extern "C" int oq_softmax_bwd(const void* p, const void* gp, void* gs, int dtype, int64_t rows, int64_t cols,
-                              float alpha, void* stream) {
+                              float alpha, int causal, void* stream) {
+    OQ_CHECK_ARG(!causal || rows % cols == 0, "oq_softmax_bwd: causal needs square [T,T] problems");
     OQ_CHECK_ARG(p && gp && gs, "oq_softmax_bwd: null pointer");
     OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 64 * 8 * SM_CH, "oq_softmax_bwd: cols %lld", (long long)cols);
     const int64_t grid = (rows + 3) / 4 < 8192 ? (rows + 3) / 4 : 8192;
     hipStream_t st = (hipStream_t)stream;
     DT_SWITCH("oq_softmax_bwd", dtype,
-              hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)p, (const float*)gp, (float*)gs, rows, cols, alpha),
-              hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)p, (const bf16_t*)gp, (bf16_t*)gs, rows, cols, alpha));
+              hipLaunchKernelGGL((softmax_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)p, (const float*)gp, (float*)gs, rows, cols, alpha, causal),
+              hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)p, (const bf16_t*)gp, (bf16_t*)gs, rows, cols, alpha, causal));
 }
 
 extern "C" int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, int dtype, int64_t n, float gscale,

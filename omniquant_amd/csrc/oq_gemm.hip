@@ -37,7 +37,7 @@ struct GemmP {
     int a_kc, b_kc;
     float alpha;
     int64_t batch_i, sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
-    int tiles_n, tiles_m, nmajor;
+    int tiles_n, tiles_m, nmajor, tri;
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -160,23 +160,28 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    if (p.tri == 1 && n0 >= m0 + BM) return;               // causal: tile entirely above the diagonal
     u32x4 ra[4], rb[4];
-    const int64_t nt = (p.K + BK - 1) / BK;
+    // causal contraction ranges (tri 2: k < m0+BM, tri 3: k >= m0), in K-tiles of 64
+    int64_t kend = p.K;
+    if (p.tri == 2 && m0 + BM < kend) kend = m0 + BM;
+    const int64_t t0 = p.tri == 3 ? m0 / BK : 0;
+    const int64_t nt = (kend + BK - 1) / BK;
     int64_t offa[4], offb[4];
     if (FAST) {
         tile_offsets<AKC>(p.lda, m0, p.M, tid, offa);
         tile_offsets<BKC>(p.ldb, n0, p.N, tid, offb);
-        load_tile_fast<AKC>(A, p.lda, 0, offa, ra);
-        load_tile_fast<BKC>(B, p.ldb, 0, offb, rb);
+        load_tile_fast<AKC>(A, p.lda, t0 * BK, offa, ra);
+        load_tile_fast<BKC>(B, p.ldb, t0 * BK, offb, rb);
     } else {
-        load_tile<AKC>(A, p.lda, m0, 0, p.M, p.K, tid, ra);
-        load_tile<BKC>(B, p.ldb, n0, 0, p.N, p.K, tid, rb);
+        load_tile<AKC>(A, p.lda, m0, t0 * BK, p.M, p.K, tid, ra);
+        load_tile<BKC>(B, p.ldb, n0, t0 * BK, p.N, p.K, tid, rb);
     }
     store_tile<AKC>(smem, tid, ra);
     store_tile<BKC>(smem + TILE_BYTES, tid, rb);
     __syncthreads();
     int cur = 0;
-    for (int64_t t = 0; t < nt; ++t) {
+    for (int64_t t = t0; t < nt; ++t) {
         const bool more = t + 1 < nt;
         if (more) {
             if (FAST) {
@@ -393,7 +398,17 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
     frag_bases<BKC, 2 * P3_BN>(wn * 64, lane, bb);
     const uint32_t lds_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
 
-    const int nt = (int)(p.K / BK);
+    if (p.tri == 1 && n0 >= m0 + P3_BM) return;            // causal: tile entirely above the diagonal
+    int64_t kend = p.K;
+    if (p.tri == 2 && m0 + P3_BM < kend) kend = m0 + P3_BM;
+    const int t0 = p.tri == 3 ? (int)(m0 / BK) : 0;
+    const int nt = (int)(kend / BK) - t0;                  // K-tiles of this tile's contraction range
+    if (t0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ga[q] += (int64_t)t0 * astep;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) gb[q] += (int64_t)t0 * bstep;
+    }
     auto issue = [&](int stage) {
         char* sa = smem + stage * P3_STAGE + wid * 1024;
 #pragma unroll
@@ -555,7 +570,11 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int64_t k0 = 0; k0 < p.K; k0 += FK) {
+    if (p.tri == 1 && n0 >= m0 + FM) return;
+    int64_t kend = p.K;
+    if (p.tri == 2 && m0 + FM < kend) kend = m0 + FM;
+    const int64_t kbeg = p.tri == 3 ? m0 : 0;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += FK) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int idx = tid + 256 * e;   // 0..1023
@@ -615,7 +634,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
 extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias, int64_t M, int64_t N, int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
                        float alpha, int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o,
-                       int64_t sb_i, int64_t sc_o, int64_t sc_i, void* stream) {
+                       int64_t sb_i, int64_t sc_o, int64_t sc_i, int tri_mode, void* stream) {
     OQ_CHECK_ARG(a && bm && c, "oq_gemm: null operand");
     OQ_CHECK_ARG(M > 0 && N > 0 && K > 0 && batch_o > 0 && batch_i > 0, "oq_gemm: empty problem M=%lld N=%lld K=%lld",
                  (long long)M, (long long)N, (long long)K);
@@ -625,6 +644,10 @@ extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias
     p.a = a; p.b = bm; p.c = c; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.a_kc = a_kc; p.b_kc = b_kc; p.alpha = alpha; p.batch_i = batch_i;
     p.sa_o = sa_o; p.sa_i = sa_i; p.sb_o = sb_o; p.sb_i = sb_i; p.sc_o = sc_o; p.sc_i = sc_i;
+    OQ_CHECK_ARG(tri_mode >= 0 && tri_mode <= 3, "oq_gemm: tri_mode %d", tri_mode);
+    OQ_CHECK_ARG(tri_mode == 0 || (tri_mode == 1 ? M == N : true), "oq_gemm: tri_mode 1 needs a square output");
+    OQ_CHECK_ARG(tri_mode < 2 || (K % 256 == 0 || K < 256), "oq_gemm: causal contraction needs K %% 256 == 0 (or K < 256)");
+    p.tri = tri_mode;
     hipStream_t st = (hipStream_t)stream;
     if (in_dtype == OQ_BF16) {
         // 16-byte vector loads / 8-16-byte stores

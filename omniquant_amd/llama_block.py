@@ -93,17 +93,18 @@ class QuantLlamaAttention(nn.Module):
         # head-wise (per head, per token) fake quant over head_dim; repeat_kv commutes with it
         q = self.qkt_matmul.quant_x1(q)
         k = self.qkt_matmul.quant_x2(k)
-        scores = self.qkt_matmul.scores(q, k)                       # [bs, nh, T, T], unscaled
         mask = None
         if attention_mask is not None:
             if attention_mask.size() != (bsz, 1, q_len, q_len):
                 raise ValueError(f"Attention mask should be of size {(bsz, 1, q_len, q_len)}, but is "
                                  f"{attention_mask.size()}")
             mask = attention_mask[0, 0]
-        probs = ops.SoftmaxFn.apply(scores, mask, 1.0 / math.sqrt(hd))   # scale, +mask, clamp, f32 softmax
+        causal = ops.mask_is_causal(attention_mask)   # exact causal mask -> the masked half is skipped everywhere
+        scores = self.qkt_matmul.scores(q, k, causal)               # [bs, nh, T, T], unscaled
+        probs = ops.SoftmaxFn.apply(scores, mask, 1.0 / math.sqrt(hd), causal)   # scale, +mask, clamp, f32 softmax
         probs = self.pv_matmul.quant_x1(probs)
         v = self.pv_matmul.quant_x2(v)
-        attn = self.pv_matmul.apply_probs(probs, v)                # [bs, T, nh, hd]
+        attn = self.pv_matmul.apply_probs(probs, v, causal)        # [bs, T, nh, hd]
         attn = self.o_proj(attn.view(bsz, q_len, self.hidden_size))
         return attn, None, None
 

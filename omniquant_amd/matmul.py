@@ -36,13 +36,14 @@ class QuantMatMul(nn.Module):
         return x2
 
     # ---- HIP GEMM entry points on the [bs, T, heads, hd] layout ------------------------------------------
-    def scores(self, q, k):
-        """q [bs,T,nh,hd], k [bs,Tk,nkv,hd] -> q @ k^T  [bs,nh,T,Tk]"""
-        return ops.AttnScoresFn.apply(q, k)
+    def scores(self, q, k, causal=False):
+        """q [bs,T,nh,hd], k [bs,Tk,nkv,hd] -> q @ k^T  [bs,nh,T,Tk].  causal=True: only tiles on/below the
+        diagonal are computed (the rest is never read by the causal softmax)."""
+        return ops.AttnScoresFn.apply(q, k, causal)
 
-    def apply_probs(self, p, v):
+    def apply_probs(self, p, v, causal=False):
         """p [bs,nh,T,Tk], v [bs,Tk,nkv,hd] -> p @ v  [bs,T,nh,hd]"""
-        return ops.AttnPVFn.apply(p, v)
+        return ops.AttnPVFn.apply(p, v, causal)
 
     def forward(self, x1, x2):
         """Generic x1 @ x2 with x1 [..., M, K], x2 [..., K, N] (reference call shape)."""

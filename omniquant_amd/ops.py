@@ -4,6 +4,7 @@ Each Function's forward AND backward are hand-written HIP kernels; PyTorch only 
 the graph.  Activations are float32 (parity mode: exact-f32 MFMA) or bfloat16 (production: bf16 MFMA).
 """
 import math
+import os
 
 import torch
 
@@ -118,7 +119,7 @@ def fake_quant(x, nbits, seg=None, up=None, low=None, symmetric=False, out_dtype
 # GEMM
 # ------------------------------------------------------------------------------------------------------
 def gemm(a, b, c, M, N, K, lda, ldb, ldc, a_kc, b_kc, bias=None, alpha=1.0, batch_o=1, batch_i=1,
-         sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0):
+         sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, tri=0):
     """Raw strided-batched GEMM on device buffers (element offsets/strides)."""
     for t in (a, b, c):
         if not t.is_cuda:
@@ -128,7 +129,7 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, a_kc, b_kc, bias=None, alpha=1.0, batc
     es_in, es_out = a.element_size(), c.element_size()
     C.call("oq_gemm", a.data_ptr() + a_off * es_in, b.data_ptr() + b_off * es_in, c.data_ptr() + c_off * es_out,
            C.fptr(bias), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc), C.dt(a), C.dt(c), float(alpha),
-           batch_o, batch_i, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], C.stream())
+           batch_o, batch_i, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], int(tri), C.stream())
 
 
 class LinearFn(torch.autograd.Function):
@@ -177,17 +178,19 @@ class AttnScoresFn(torch.autograd.Function):
     models/int_llama_layer.py:143).  q [bs,T,nh,hd], k [bs,Tk,nkv,hd] -> S [bs,nh,T,Tk]."""
 
     @staticmethod
-    def forward(ctx, q, k):
+    def forward(ctx, q, k, causal=False):
         q, k = q.contiguous(), k.contiguous()
         bs, T, nh, hd = q.shape
         Tk, nkv = k.shape[1], k.shape[2]
         rep = nh // nkv
+        causal = bool(causal) and T == Tk
         s = torch.empty((bs, nh, T, Tk), dtype=q.dtype, device=q.device)
         for b in range(bs):
             gemm(q, k, s, T, Tk, hd, nh * hd, nkv * hd, Tk, True, True, batch_o=nkv, batch_i=rep,
                  sa=(rep * hd, hd), sb=(hd, 0), sc=(rep * T * Tk, T * Tk),
-                 a_off=b * T * nh * hd, b_off=b * Tk * nkv * hd, c_off=b * nh * T * Tk)
+                 a_off=b * T * nh * hd, b_off=b * Tk * nkv * hd, c_off=b * nh * T * Tk, tri=1 if causal else 0)
         ctx.save_for_backward(q, k)
+        ctx.causal = causal
         return s
 
     @staticmethod
@@ -200,16 +203,16 @@ class AttnScoresFn(torch.autograd.Function):
         gq = torch.empty_like(q)
         gk_full = torch.empty((bs, Tk, nh, hd), dtype=k.dtype, device=k.device)
         for b in range(bs):
-            # dQ[t,d] = sum_t' dS[t,t'] K[t',d]
+            # dQ[t,d] = sum_t' dS[t,t'] K[t',d]          (causal: t' < m0 + tile)
             gemm(gs, k, gq, T, hd, Tk, Tk, nkv * hd, nh * hd, True, False, batch_o=nkv, batch_i=rep,
                  sa=(rep * T * Tk, T * Tk), sb=(hd, 0), sc=(rep * hd, hd),
-                 a_off=b * nh * T * Tk, b_off=b * Tk * nkv * hd, c_off=b * T * nh * hd)
-            # dK[t',d] = sum_t dS[t,t'] Q[t,d]    (per q-head, reduced over rep below)
+                 a_off=b * nh * T * Tk, b_off=b * Tk * nkv * hd, c_off=b * T * nh * hd, tri=2 if ctx.causal else 0)
+            # dK[t',d] = sum_t dS[t,t'] Q[t,d]    (per q-head, reduced over rep below; causal: t >= m0)
             gemm(gs, q, gk_full, Tk, hd, T, Tk, nh * hd, nh * hd, False, False, batch_o=nh, batch_i=1,
                  sa=(T * Tk, 0), sb=(hd, 0), sc=(hd, 0),
-                 a_off=b * nh * T * Tk, b_off=b * T * nh * hd, c_off=b * Tk * nh * hd)
+                 a_off=b * nh * T * Tk, b_off=b * T * nh * hd, c_off=b * Tk * nh * hd, tri=3 if ctx.causal else 0)
         gk = gk_full if rep == 1 else gk_full.view(bs, Tk, nkv, rep, hd).sum(dim=3)
-        return gq, gk
+        return gq, gk, None
 
 
 class AttnPVFn(torch.autograd.Function):
@@ -217,17 +220,19 @@ class AttnPVFn(torch.autograd.Function):
     v [bs,Tk,nkv,hd] -> o [bs,T,nh,hd]."""
 
     @staticmethod
-    def forward(ctx, p, v):
+    def forward(ctx, p, v, causal=False):
         p, v = p.contiguous(), v.contiguous()
         bs, nh, T, Tk = p.shape
         nkv, hd = v.shape[2], v.shape[3]
         rep = nh // nkv
+        causal = bool(causal) and T == Tk
         o = torch.empty((bs, T, nh, hd), dtype=p.dtype, device=p.device)
         for b in range(bs):
             gemm(p, v, o, T, hd, Tk, Tk, nkv * hd, nh * hd, True, False, batch_o=nkv, batch_i=rep,
                  sa=(rep * T * Tk, T * Tk), sb=(hd, 0), sc=(rep * hd, hd),
-                 a_off=b * nh * T * Tk, b_off=b * Tk * nkv * hd, c_off=b * T * nh * hd)
+                 a_off=b * nh * T * Tk, b_off=b * Tk * nkv * hd, c_off=b * T * nh * hd, tri=2 if causal else 0)
         ctx.save_for_backward(p, v)
+        ctx.causal = causal
         return o
 
     @staticmethod
@@ -240,16 +245,16 @@ class AttnPVFn(torch.autograd.Function):
         gp = torch.empty_like(p)
         gv_full = torch.empty((bs, Tk, nh, hd), dtype=v.dtype, device=v.device)
         for b in range(bs):
-            # dP[t,t'] = sum_d dO[t,d] V[t',d]
+            # dP[t,t'] = sum_d dO[t,d] V[t',d]          (causal: tiles above the diagonal are skipped)
             gemm(go, v, gp, T, Tk, hd, nh * hd, nkv * hd, Tk, True, True, batch_o=nkv, batch_i=rep,
                  sa=(rep * hd, hd), sb=(hd, 0), sc=(rep * T * Tk, T * Tk),
-                 a_off=b * T * nh * hd, b_off=b * Tk * nkv * hd, c_off=b * nh * T * Tk)
-            # dV[t',d] = sum_t P[t,t'] dO[t,d]
+                 a_off=b * T * nh * hd, b_off=b * Tk * nkv * hd, c_off=b * nh * T * Tk, tri=1 if ctx.causal else 0)
+            # dV[t',d] = sum_t P[t,t'] dO[t,d]           (causal: t >= m0)
             gemm(p, go, gv_full, Tk, hd, T, Tk, nh * hd, nh * hd, False, False, batch_o=nh, batch_i=1,
                  sa=(T * Tk, 0), sb=(hd, 0), sc=(hd, 0),
-                 a_off=b * nh * T * Tk, b_off=b * T * nh * hd, c_off=b * Tk * nh * hd)
+                 a_off=b * nh * T * Tk, b_off=b * T * nh * hd, c_off=b * Tk * nh * hd, tri=3 if ctx.causal else 0)
         gv = gv_full if rep == 1 else gv_full.view(bs, Tk, nkv, rep, hd).sum(dim=3)
-        return gp, gv
+        return gp, gv, None
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -358,18 +363,21 @@ class SoftmaxFn(torch.autograd.Function):
     """p = softmax(max(s*alpha + mask, finfo.min)) in f32 (models/int_llama_layer.py:143-160)."""
 
     @staticmethod
-    def forward(ctx, s, mask, alpha):
+    def forward(ctx, s, mask, alpha, causal=False):
         s = s.contiguous()
         cols = s.shape[-1]
         rows = s.numel() // cols
         p = torch.empty_like(s)
         m32, mrows = None, 0
-        if mask is not None:
+        causal = bool(causal) and s.shape[-2] == cols
+        if mask is not None and not causal:
             m32 = mask.detach().float().contiguous().view(-1, cols)
             mrows = m32.shape[0]
-        C.call("oq_softmax_fwd", C.ptr(s), C.ptr(p), C.dt(s), rows, cols, float(alpha), C.fptr(m32), mrows, C.stream())
+        C.call("oq_softmax_fwd", C.ptr(s), C.ptr(p), C.dt(s), rows, cols, float(alpha), C.fptr(m32), mrows, int(causal),
+               C.stream())
         ctx.save_for_backward(p)
         ctx.alpha = float(alpha)
+        ctx.causal = causal
         return p
 
     @staticmethod
@@ -379,8 +387,9 @@ class SoftmaxFn(torch.autograd.Function):
         cols = p.shape[-1]
         rows = p.numel() // cols
         gs = torch.empty_like(p)
-        C.call("oq_softmax_bwd", C.ptr(p), C.ptr(gp), C.ptr(gs), C.dt(p), rows, cols, ctx.alpha, C.stream())
-        return gs, None, None
+        C.call("oq_softmax_bwd", C.ptr(p), C.ptr(gp), C.ptr(gs), C.dt(p), rows, cols, ctx.alpha, int(ctx.causal),
+               C.stream())
+        return gs, None, None, None
 
 
 class AddFn(torch.autograd.Function):
@@ -440,6 +449,32 @@ class ScaleByTensor:
     def apply_raw(g, gl):
         # gl is a 0-dim tensor; avoid a host sync: multiply on device (plumbing op, 1 launch)
         return g * gl.to(g.dtype)
+
+
+def mask_is_causal(attention_mask):
+    """True iff the additive attention mask ([T,T] or [bs,1,T,T]) is exactly the causal one (0 on/below the
+    diagonal, <= -1e30 above it, so masked probabilities are exactly 0).  The check costs one host sync, so its
+    result is cached ON the tensor object (or on the base tensor of an expand()/index view) together with the
+    tensor's version counter; the causal fast path then skips the masked half of every attention GEMM and of the
+    softmax."""
+    if attention_mask is None or attention_mask.dim() not in (2, 4) or attention_mask.shape[-1] != attention_mask.shape[-2]:
+        return False
+    if os.environ.get("OQ_NO_CAUSAL_FASTPATH"):      # A/B switch: always take the dense masked path
+        return False
+    root = attention_mask._base if attention_mask._base is not None else attention_mask
+    tag = (root._version, tuple(attention_mask.shape))
+    cached = getattr(root, "_oq_causal", None)
+    if cached is not None and cached[0] == tag:
+        return cached[1]
+    T = attention_mask.shape[-1]
+    m = attention_mask.reshape(-1, T, T).float()
+    lower = torch.tril(torch.ones(T, T, dtype=torch.bool, device=m.device))
+    hit = bool(T > 1 and ((m == 0) == lower).all().item() and (m[:, ~lower] <= -1e30).all().item())
+    try:
+        root._oq_causal = (tag, hit)
+    except Exception:
+        pass
+    return hit
 
 
 def cast(x, dtype):

@@ -49,16 +49,17 @@ class QuantOPTAttention(nn.Module):
         k = self.qkt_matmul.quant_x2(self.k_proj(hq, True))
         v = self.pv_matmul.quant_x2(self.v_proj(hq, True))
         q, k, v = (t.view(bsz, tgt_len, nh, hd) for t in (q, k, v))
-        scores = self.qkt_matmul.scores(q, k)
         mask = None
         if attention_mask is not None:
             if attention_mask.size() != (bsz, 1, tgt_len, tgt_len):
                 raise ValueError(f"Attention mask should be of size {(bsz, 1, tgt_len, tgt_len)}, but is "
                                  f"{attention_mask.size()}")
             mask = attention_mask[0, 0]
-        probs = ops.SoftmaxFn.apply(scores, mask, 1.0)
+        causal = ops.mask_is_causal(attention_mask)
+        scores = self.qkt_matmul.scores(q, k, causal)
+        probs = ops.SoftmaxFn.apply(scores, mask, 1.0, causal)
         probs = self.pv_matmul.quant_x1(probs)
-        attn = self.pv_matmul.apply_probs(probs, v).view(bsz, tgt_len, self.embed_dim)
+        attn = self.pv_matmul.apply_probs(probs, v, causal).view(bsz, tgt_len, self.embed_dim)
         return self.out_proj(attn), None, None
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):

@@ -354,3 +354,32 @@ def test_full_size_properties():
     ops.gemm(dY, X, dW, N, K, Tn, N, K, K, False, False)
     chk = dY.float().T @ X.float().sum(1)
     assert torch.allclose(dW.sum(1), chk, rtol=2e-3, atol=2e-2 * float(chk.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Tn", [128, 512, 768])
+def test_causal_attention_fast_path(dtype, Tn):
+    """Causal fast path (tile-skipping GEMM modes + causal softmax) vs the dense path with the additive mask:
+    forward output and all three input gradients must agree (masked probabilities are exactly 0 in both)."""
+    from omniquant_amd import ops
+    bs, nh, nkv, hd = 1, 4, 2, 64
+    g = torch.Generator().manual_seed(Tn)
+    q = torch.randn(bs, Tn, nh, hd, generator=g)
+    k = torch.randn(bs, Tn, nkv, hd, generator=g)
+    v = torch.randn(bs, Tn, nkv, hd, generator=g)
+    Go = torch.randn(bs, Tn, nh, hd, generator=g).to(dtype).to(DEV)
+    mask = torch.triu(torch.full((Tn, Tn), torch.finfo(torch.float32).min), 1).to(DEV)
+    assert ops.mask_is_causal(mask)
+    assert not ops.mask_is_causal(torch.zeros(Tn, Tn, device=DEV))
+    outs = []
+    for causal in (False, True):
+        qd, kd, vd = (t.clone().to(dtype).to(DEV).requires_grad_(True) for t in (q, k, v))
+        s = ops.AttnScoresFn.apply(qd, kd, causal)
+        p = ops.SoftmaxFn.apply(s, mask, 1.0 / math.sqrt(hd), causal)
+        o = ops.AttnPVFn.apply(p, vd, causal)
+        (o.float() * Go.float()).sum().backward()
+        outs.append((o, qd.grad, kd.grad, vd.grad))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for name, a, b in zip(("o", "gq", "gk", "gv"), outs[0], outs[1]):
+        sc = float(a.float().abs().max())
+        assert_close(b.detach().float() / sc, (a.detach().float() / sc).cpu().numpy(), tol, tol, f"causal {name}")
