@@ -144,6 +144,27 @@ int oq_adamw(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_
              float beta1, float beta2, float eps, float wd, float* step_ptr, const float* norm, void* stream);
 int oq_truncate(float* x, int64_t n, float thr, void* stream);
 
+/* LET vector algebra of one block (norm weights/biases and the bias side of smooth_ln_fcs / smooth_fc_fc /
+ * smooth_q_k, models/transformation.py:24-69) in one launch; all vectors f32 [n] (n = hidden size):
+ *   ln1_tw = ln1_w/s1, ln1_tb = (ln1_b-h1)/s1 (ln1_b NULL: (-1*h1)/s1), same for ln2 with s3/h3;
+ *   b_q = (bq0+ws_q)/t, b_k = (bk0+ws_k)*t, b_v = ((bv0+ws_v)-h2)/s2, b_o = bo0+ws_o   (bias NULL: ws alone)
+ * s1/h1 = qkv scale/shift, s2/h2 = out, s3/h3 = fc1, t = qkt, ws_* = W@shift from oq_fakequant_fwd.
+ * _bwd takes the gradients of the eight outputs and returns those of the seven LET vectors and of the four ws. */
+int oq_let_vectors_fwd(int64_t n, const float* s1, const float* h1, const float* s2, const float* h2,
+                       const float* s3, const float* h3, const float* t, const float* ln1_w, const float* ln1_b,
+                       const float* ln2_w, const float* ln2_b, const float* ws_q, const float* ws_k, const float* ws_v,
+                       const float* ws_o, const float* bq0, const float* bk0, const float* bv0, const float* bo0,
+                       float* ln1_tw, float* ln1_tb, float* ln2_tw, float* ln2_tb, float* b_q, float* b_k, float* b_v,
+                       float* b_o, void* stream);
+int oq_let_vectors_bwd(int64_t n, const float* s1, const float* h1, const float* s2, const float* h2,
+                       const float* s3, const float* h3, const float* t, const float* ln1_w, const float* ln1_b,
+                       const float* ln2_w, const float* ln2_b, const float* ws_q, const float* ws_k, const float* ws_v,
+                       const float* ws_o, const float* bq0, const float* bk0, const float* bv0, const float* bo0,
+                       const float* g_ln1_tw, const float* g_ln1_tb, const float* g_ln2_tw, const float* g_ln2_tb,
+                       const float* g_b_q, const float* g_b_k, const float* g_b_v, const float* g_b_o,
+                       float* g_s1, float* g_h1, float* g_s2, float* g_h2, float* g_s3, float* g_h3, float* g_t,
+                       float* g_ws_q, float* g_ws_k, float* g_ws_v, float* g_ws_o, void* stream);
+
 /* dtype conversion with round-to-nearest-even */
 int oq_cast(const void* x, int src_dtype, void* y, int dst_dtype, int64_t n, void* stream);
 

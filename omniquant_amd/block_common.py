@@ -32,32 +32,66 @@ class QuantBlockMixin:
         return [m for m in self.modules() if isinstance(m, QuantLinear)]
 
     def _truncate_scales(self):
+        arena = self.__dict__.get("_arena_truncate")
+        if arena is not None:
+            arena()                      # all LET scales are contiguous in the optimizer's arena: one launch
+            return
         with torch.no_grad():
             for name, p in self.named_parameters():
                 if "smooth_scale" in name:
                     L.truncate_number(p)
 
+    def _f32c(self, t):
+        """float32 copy of a frozen norm weight / bias buffer, cached (they never change during calibration)."""
+        if t is None:
+            return None
+        if t.dtype == torch.float32:
+            return t
+        cache = self.__dict__.setdefault("_f32_cache", {})
+        key = (id(t), t._version)
+        hit = cache.get(id(t))
+        if hit is None or hit[0] != key:
+            cache[id(t)] = (key, t.detach().float().contiguous(), t)     # keep `t` alive so id() stays unique
+        return cache[id(t)][1]
+
+    def _let_temporaries(self, out_dtype):
+        """Fused LET path: 6 fused transform+fake-quant kernels (one per smoothed linear) + ONE vector kernel for
+        every norm weight/bias and projection bias.  Returns {module: (temp_weight, temp_bias)} and the norm temps."""
+        nm = self._let_names()
+        from . import ops
+        specs = L.block_let_specs(nm, self, None)
+        wq, ws = {}, {}
+        for mod, sp in specs.items():
+            if sp.shift is not None:
+                wq[mod], ws[mod] = mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype, col_mul=sp.col_mul,
+                                                                 row_div=sp.row_div, row_mul=sp.row_mul, shift=sp.shift)
+            else:
+                wq[mod] = mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype)
+        q, k, v, o, ln1, ln2 = nm["q"], nm["k"], nm["v"], nm["o"], nm["ln1"], nm["ln2"]
+        f = self._f32c
+        ln1_tw, ln1_tb, ln2_tw, ln2_tb, b_q, b_k, b_v, b_o = ops.LetVectorsFn.apply(
+            self.qkv_smooth_scale, self.qkv_smooth_shift, self.out_smooth_scale, self.out_smooth_shift,
+            self.fc1_smooth_scale, self.fc1_smooth_shift, self.qkt_smooth_scale,
+            ws[q], ws[k], ws[v], ws[o], f(ln1.weight), f(getattr(ln1, "bias", None)), f(ln2.weight),
+            f(getattr(ln2, "bias", None)), f(q.bias), f(k.bias), f(v.bias), f(o.bias))
+        bias = {q: b_q, k: b_k, v: b_v, o: b_o, nm["last"]: nm["last"].bias}
+        for fc in nm["fc1"]:
+            bias[fc] = ws[fc] if fc.bias is None else f(fc.bias) + ws[fc]
+        return wq, bias, (ln1_tw, ln1_tb), (ln2_tw, ln2_tb)
+
     def smooth_and_quant_temporary(self):
-        """LET re-parameterisation + weight fake-quant of every linear: ONE fused kernel per weight matrix
-        (reference: ~25 eager passes per matrix, models/int_llama_layer.py:279-307)."""
+        """LET re-parameterisation + weight fake-quant of every linear: ONE fused kernel per weight matrix plus one
+        vector kernel (reference: ~25 eager passes per matrix, models/int_llama_layer.py:279-307)."""
         nm = self._let_names()
         dt = self.compute_dtype
         if self.let:
             self._truncate_scales()
-            specs = L.block_let_specs(nm, self, None)
-            for ln, key in ((nm["ln1"], "qkv"), (nm["ln2"], "fc1")):
-                ln.temp_weight, ln.temp_bias = L.ln_temporaries(
-                    ln, getattr(self, f"{key}_smooth_scale"), getattr(self, f"{key}_smooth_shift"))
+            wq, bias, t1, t2 = self._let_temporaries(dt)
+            for ln, (tw, tb) in ((nm["ln1"], t1), (nm["ln2"], t2)):
+                ln.temp_weight, ln.temp_bias = tw, tb
                 ln.use_temporary_parameter = True
-            for mod, sp in specs.items():
-                if sp.shift is not None:
-                    mod.temp_weight, ws = mod.weight_quantizer.quantize(
-                        mod.weight, out_dtype=dt, col_mul=sp.col_mul, row_div=sp.row_div, row_mul=sp.row_mul,
-                        shift=sp.shift)
-                    mod.temp_bias = sp.bias_fn(ws)
-                else:
-                    mod.temp_weight = mod.weight_quantizer.quantize(mod.weight, out_dtype=dt)
-                    mod.temp_bias = mod.bias
+            for mod in wq:
+                mod.temp_weight, mod.temp_bias = wq[mod], bias[mod]
                 mod.use_temporary_parameter = True
         else:
             for mod in self._quant_linears():
@@ -80,25 +114,19 @@ class QuantBlockMixin:
         nm = self._let_names()
         if self.let:
             self._truncate_scales()
-            specs = L.block_let_specs(nm, self, None)
-            for ln, key in ((nm["ln1"], "qkv"), (nm["ln2"], "fc1")):
-                tw, tb = L.ln_temporaries(ln, getattr(self, f"{key}_smooth_scale"), getattr(self, f"{key}_smooth_shift"))
+            wq, bias, t1, t2 = self._let_temporaries(torch.float32)
+            for ln, (tw, tb) in ((nm["ln1"], t1), (nm["ln2"], t2)):
                 ln.use_temporary_parameter = False
                 if hasattr(ln, "bias"):
                     del ln.bias
                 ln.register_buffer("bias", tb)
                 ln.weight = tw
-            for mod, sp in specs.items():
-                if sp.shift is not None:
-                    w, ws = mod.weight_quantizer.quantize(mod.weight, out_dtype=torch.float32, col_mul=sp.col_mul,
-                                                          row_div=sp.row_div, row_mul=sp.row_mul, shift=sp.shift)
-                    b = sp.bias_fn(ws)
+            for mod in wq:
+                if bias[mod] is not None and mod is not nm["last"]:
                     if hasattr(mod, "bias"):
                         del mod.bias
-                    mod.register_buffer("bias", b)
-                else:
-                    w = mod.weight_quantizer.quantize(mod.weight, out_dtype=torch.float32)
-                mod.weight = w
+                    mod.register_buffer("bias", bias[mod])
+                mod.weight = wq[mod]
                 mod.use_temporary_parameter = False
         else:
             for mod in self._quant_linears():

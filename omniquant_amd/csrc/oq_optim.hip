@@ -109,3 +109,117 @@ extern "C" int oq_truncate(float* x, int64_t n, float thr, void* stream) {
     OQ_CHECK_LAUNCH("oq_truncate");
     return OQ_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// LET vector algebra of one block in ONE launch (forward) + ONE launch (backward).
+// Replaces the [hidden]-sized eager ops of models/transformation.py:24-69 (norm weight/bias re-parameterisation and
+// the bias side of smooth_ln_fcs / smooth_fc_fc / smooth_q_k):
+//   ln1_tw = ln1_w / s1            ln1_tb = (ln1_b - h1) / s1      (ln1_b NULL: (-1*h1)/s1)
+//   ln2_tw = ln2_w / s3            ln2_tb = (ln2_b - h3) / s3
+//   b_q = (bq0 + ws_q) / t         b_k = (bk0 + ws_k) * t          (bias NULL: ws alone)
+//   b_v = ((bv0 + ws_v) - h2) / s2 b_o = bo0 + ws_o
+// with s1/h1 = qkv scale/shift, s2/h2 = out, s3/h3 = fc1, t = qkt, ws_* = W @ shift from oq_fakequant_fwd.
+// The reference launches ~10 tiny kernels for this and ~25 more in autograd; each costs ~4-5 us inside the graph.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct LetV {
+    int64_t n;
+    const float *s1, *h1, *s2, *h2, *s3, *h3, *t;
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    const float *ws_q, *ws_k, *ws_v, *ws_o, *bq0, *bk0, *bv0, *bo0;
+    float *ln1_tw, *ln1_tb, *ln2_tw, *ln2_tb, *b_q, *b_k, *b_v, *b_o;                 // fwd outputs / bwd: incoming grads
+    float *g_s1, *g_h1, *g_s2, *g_h2, *g_s3, *g_h3, *g_t, *g_ws_q, *g_ws_k, *g_ws_v, *g_ws_o;   // bwd outputs
+};
+
+__global__ void __launch_bounds__(256) letvec_fwd_kernel(LetV p) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s1 = p.s1[i], h1 = p.h1[i], s2 = p.s2[i], h2 = p.h2[i], s3 = p.s3[i], h3 = p.h3[i], t = p.t[i];
+        p.ln1_tw[i] = p.ln1_w[i] / s1;
+        p.ln1_tb[i] = p.ln1_b ? (p.ln1_b[i] - h1) / s1 : (-1.f * h1) / s1;
+        p.ln2_tw[i] = p.ln2_w[i] / s3;
+        p.ln2_tb[i] = p.ln2_b ? (p.ln2_b[i] - h3) / s3 : (-1.f * h3) / s3;
+        const float aq = p.bq0 ? p.bq0[i] + p.ws_q[i] : p.ws_q[i];
+        const float ak = p.bk0 ? p.bk0[i] + p.ws_k[i] : p.ws_k[i];
+        const float av = p.bv0 ? p.bv0[i] + p.ws_v[i] : p.ws_v[i];
+        p.b_q[i] = aq / t;
+        p.b_k[i] = ak * t;
+        p.b_v[i] = (av - h2) / s2;
+        p.b_o[i] = p.bo0 ? p.bo0[i] + p.ws_o[i] : p.ws_o[i];
+    }
+}
+
+// the struct's forward-output slots carry the INCOMING gradients here
+__global__ void __launch_bounds__(256) letvec_bwd_kernel(LetV p) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < p.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float s1 = p.s1[i], h1 = p.h1[i], s2 = p.s2[i], h2 = p.h2[i], s3 = p.s3[i], h3 = p.h3[i], t = p.t[i];
+        const float g1w = p.ln1_tw[i], g1b = p.ln1_tb[i], g2w = p.ln2_tw[i], g2b = p.ln2_tb[i];
+        const float gq = p.b_q[i], gk = p.b_k[i], gv = p.b_v[i], go = p.b_o[i];
+        const float n1 = p.ln1_b ? p.ln1_b[i] - h1 : -1.f * h1;
+        const float n3 = p.ln2_b ? p.ln2_b[i] - h3 : -1.f * h3;
+        p.g_s1[i] = -(g1w * p.ln1_w[i] + g1b * n1) / (s1 * s1);
+        p.g_h1[i] = -g1b / s1;
+        p.g_s3[i] = -(g2w * p.ln2_w[i] + g2b * n3) / (s3 * s3);
+        p.g_h3[i] = -g2b / s3;
+        const float aq = p.bq0 ? p.bq0[i] + p.ws_q[i] : p.ws_q[i];
+        const float ak = p.bk0 ? p.bk0[i] + p.ws_k[i] : p.ws_k[i];
+        const float av = p.bv0 ? p.bv0[i] + p.ws_v[i] : p.ws_v[i];
+        p.g_t[i] = -gq * aq / (t * t) + gk * ak;
+        p.g_ws_q[i] = gq / t;
+        p.g_ws_k[i] = gk * t;
+        p.g_s2[i] = -gv * (av - h2) / (s2 * s2);
+        p.g_h2[i] = -gv / s2;
+        p.g_ws_v[i] = gv / s2;
+        p.g_ws_o[i] = go;
+    }
+}
+}  // namespace
+
+extern "C" int oq_let_vectors_fwd(int64_t n, const float* s1, const float* h1, const float* s2, const float* h2,
+                                  const float* s3, const float* h3, const float* t, const float* ln1_w,
+                                  const float* ln1_b, const float* ln2_w, const float* ln2_b, const float* ws_q,
+                                  const float* ws_k, const float* ws_v, const float* ws_o, const float* bq0,
+                                  const float* bk0, const float* bv0, const float* bo0, float* ln1_tw, float* ln1_tb,
+                                  float* ln2_tw, float* ln2_tb, float* b_q, float* b_k, float* b_v, float* b_o,
+                                  void* stream) {
+    OQ_CHECK_ARG(n > 0 && s1 && h1 && s2 && h2 && s3 && h3 && t && ln1_w && ln2_w && ws_q && ws_k && ws_v && ws_o &&
+                     ln1_tw && ln1_tb && ln2_tw && ln2_tb && b_q && b_k && b_v && b_o,
+                 "oq_let_vectors_fwd: null pointer");
+    LetV p{};
+    p.n = n; p.s1 = s1; p.h1 = h1; p.s2 = s2; p.h2 = h2; p.s3 = s3; p.h3 = h3; p.t = t;
+    p.ln1_w = ln1_w; p.ln1_b = ln1_b; p.ln2_w = ln2_w; p.ln2_b = ln2_b;
+    p.ws_q = ws_q; p.ws_k = ws_k; p.ws_v = ws_v; p.ws_o = ws_o; p.bq0 = bq0; p.bk0 = bk0; p.bv0 = bv0; p.bo0 = bo0;
+    p.ln1_tw = ln1_tw; p.ln1_tb = ln1_tb; p.ln2_tw = ln2_tw; p.ln2_tb = ln2_tb; p.b_q = b_q; p.b_k = b_k; p.b_v = b_v; p.b_o = b_o;
+    int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(letvec_fwd_kernel, dim3(nb > 256 ? 256 : nb), dim3(256), 0, (hipStream_t)stream, p);
+    OQ_CHECK_LAUNCH("oq_let_vectors_fwd");
+    return OQ_OK;
+}
+
+extern "C" int oq_let_vectors_bwd(int64_t n, const float* s1, const float* h1, const float* s2, const float* h2,
+                                  const float* s3, const float* h3, const float* t, const float* ln1_w,
+                                  const float* ln1_b, const float* ln2_w, const float* ln2_b, const float* ws_q,
+                                  const float* ws_k, const float* ws_v, const float* ws_o, const float* bq0,
+                                  const float* bk0, const float* bv0, const float* bo0, const float* g_ln1_tw,
+                                  const float* g_ln1_tb, const float* g_ln2_tw, const float* g_ln2_tb,
+                                  const float* g_b_q, const float* g_b_k, const float* g_b_v, const float* g_b_o,
+                                  float* g_s1, float* g_h1, float* g_s2, float* g_h2, float* g_s3, float* g_h3,
+                                  float* g_t, float* g_ws_q, float* g_ws_k, float* g_ws_v, float* g_ws_o, void* stream) {
+    OQ_CHECK_ARG(n > 0 && s1 && h1 && s2 && h2 && s3 && h3 && t && ln1_w && ln2_w && ws_q && ws_k && ws_v && ws_o &&
+                     g_ln1_tw && g_ln1_tb && g_ln2_tw && g_ln2_tb && g_b_q && g_b_k && g_b_v && g_b_o && g_s1 && g_h1 &&
+                     g_s2 && g_h2 && g_s3 && g_h3 && g_t && g_ws_q && g_ws_k && g_ws_v && g_ws_o,
+                 "oq_let_vectors_bwd: null pointer");
+    LetV p{};
+    p.n = n; p.s1 = s1; p.h1 = h1; p.s2 = s2; p.h2 = h2; p.s3 = s3; p.h3 = h3; p.t = t;
+    p.ln1_w = ln1_w; p.ln1_b = ln1_b; p.ln2_w = ln2_w; p.ln2_b = ln2_b;
+    p.ws_q = ws_q; p.ws_k = ws_k; p.ws_v = ws_v; p.ws_o = ws_o; p.bq0 = bq0; p.bk0 = bk0; p.bv0 = bv0; p.bo0 = bo0;
+    p.ln1_tw = const_cast<float*>(g_ln1_tw); p.ln1_tb = const_cast<float*>(g_ln1_tb);
+    p.ln2_tw = const_cast<float*>(g_ln2_tw); p.ln2_tb = const_cast<float*>(g_ln2_tb);
+    p.b_q = const_cast<float*>(g_b_q); p.b_k = const_cast<float*>(g_b_k); p.b_v = const_cast<float*>(g_b_v);
+    p.b_o = const_cast<float*>(g_b_o);
+    p.g_s1 = g_s1; p.g_h1 = g_h1; p.g_s2 = g_s2; p.g_h2 = g_h2; p.g_s3 = g_s3; p.g_h3 = g_h3; p.g_t = g_t;
+    p.g_ws_q = g_ws_q; p.g_ws_k = g_ws_k; p.g_ws_v = g_ws_v; p.g_ws_o = g_ws_o;
+    int64_t nb = (n + 255) / 256;
+    hipLaunchKernelGGL(letvec_bwd_kernel, dim3(nb > 256 ? 256 : nb), dim3(256), 0, (hipStream_t)stream, p);
+    OQ_CHECK_LAUNCH("oq_let_vectors_bwd");
+    return OQ_OK;
+}

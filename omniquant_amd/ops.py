@@ -53,7 +53,7 @@ class FakeQuantFn(torch.autograd.Function):
         ctx.save_for_backward(w, cm, rd, rm, sh, u, l)
         ctx.cfg = (rows, cols, seg, nbits, int(symmetric))
         if wshift is None:
-            wshift = torch.zeros((), device=w.device)   # placeholder output, never used
+            wshift = torch.empty((0,), device=w.device)   # placeholder output, never used (no kernel launched)
             ctx.has_wshift = False
         else:
             ctx.has_wshift = True
@@ -449,6 +449,36 @@ class ScaleByTensor:
     def apply_raw(g, gl):
         # gl is a 0-dim tensor; avoid a host sync: multiply on device (plumbing op, 1 launch)
         return g * gl.to(g.dtype)
+
+
+class LetVectorsFn(torch.autograd.Function):
+    """All [hidden]-sized LET algebra of a block in one launch (forward) + one launch (backward):
+    norm weight/bias re-parameterisation and the bias side of smooth_ln_fcs / smooth_fc_fc / smooth_q_k
+    (models/transformation.py:24-69).  Inputs are float32 vectors of length hidden; biases may be None."""
+
+    @staticmethod
+    def forward(ctx, s1, h1, s2, h2, s3, h3, t, ws_q, ws_k, ws_v, ws_o, ln1_w, ln1_b, ln2_w, ln2_b, bq0, bk0, bv0, bo0):
+        n = s1.numel()
+        ins = [x.detach().contiguous() if x is not None else None
+               for x in (s1, h1, s2, h2, s3, h3, t, ln1_w, ln1_b, ln2_w, ln2_b, ws_q, ws_k, ws_v, ws_o, bq0, bk0, bv0, bo0)]
+        outs = [torch.empty(n, dtype=torch.float32, device=s1.device) for _ in range(8)]
+        C.call("oq_let_vectors_fwd", n, *[C.fptr(x) for x in ins], *[C.fptr(o) for o in outs], C.stream())
+        ctx.save_for_backward(*[x for x in ins if x is not None])
+        ctx.present = [x is not None for x in ins]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        saved = list(ctx.saved_tensors)
+        ins = [saved.pop(0) if pres else None for pres in ctx.present]
+        n = ins[0].numel()
+        dev = ins[0].device
+        g = [go.contiguous() if go is not None else torch.zeros(n, dtype=torch.float32, device=dev) for go in gouts]
+        res = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(11)]
+        C.call("oq_let_vectors_bwd", n, *[C.fptr(x) for x in ins], *[C.fptr(x) for x in g], *[C.fptr(x) for x in res],
+               C.stream())
+        g_s1, g_h1, g_s2, g_h2, g_s3, g_h3, g_t, g_wq, g_wk, g_wv, g_wo = res
+        return (g_s1, g_h1, g_s2, g_h2, g_s3, g_h3, g_t, g_wq, g_wk, g_wv, g_wo) + (None,) * 8
 
 
 def mask_is_causal(attention_mask):

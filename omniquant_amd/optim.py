@@ -43,6 +43,8 @@ class BlockOptimizer:
                 p.grad = self.grad[off:off + k].view(p.shape)
                 p.requires_grad_(True)
                 off += k
+        if self.n_scale:
+            qlayer.__dict__["_arena_truncate"] = self.truncate_scales     # block's truncate_number -> one launch
         self.let_lr, self.lwc_lr, self.wd = float(let_lr), float(lwc_lr), float(weight_decay)
         self.betas, self.eps = betas, float(eps)
 
