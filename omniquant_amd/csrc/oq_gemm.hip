@@ -548,6 +548,231 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Persistent variant of the 256x128x64 kernel: one workgroup per CU walks a list of output tiles and the LDS-DMA
+// stream of K-tiles never drains at a tile boundary (the first K-tiles of the next output tile are already in flight
+// while the current tile finishes and stores its result).  Removes the per-tile pipeline fill, which dominated
+// short-K problems (wgrad K = 2048: 32 K-tiles; attention scores K = 128: 2 K-tiles).  Same staggered two-group
+// schedule, ring and hazard reasoning as gemm_bf16_p3_kernel; "g" below is the workgroup's global K-tile counter.
+// ---------------------------------------------------------------------------------------------------
+struct TileCur {          // wave-uniform cursor over this workgroup's tile list
+    int k;                // index into the list (tile id = remap(blockIdx.x + k * gridDim.x))
+    int nt;               // K-tiles of the current tile
+    int t0;               // first K-tile (causal mode 3)
+    int64_t m0, n0, z;
+    bool valid;
+};
+
+__device__ __forceinline__ void tile_decode(const GemmP& p, int total, int tiles_per_z, int w, TileCur& c) {
+    // XCD-aware bijective remap of the linear work id (same formula as the non-persistent kernels)
+    const int xcd = w & 7, q = total >> 3, r = total & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+    c.z = tile / tiles_per_z;
+    const int tz = tile % tiles_per_z;
+    if (p.nmajor) { c.n0 = (int64_t)(tz / p.tiles_m) * P3_BN; c.m0 = (int64_t)(tz % p.tiles_m) * P3_BM; }
+    else { c.m0 = (int64_t)(tz / p.tiles_n) * P3_BM; c.n0 = (int64_t)(tz % p.tiles_n) * P3_BN; }
+    int64_t kend = p.K;
+    if (p.tri == 2 && c.m0 + P3_BM < kend) kend = c.m0 + P3_BM;
+    c.t0 = p.tri == 3 ? (int)(c.m0 / BK) : 0;
+    c.nt = (int)(kend / BK) - c.t0;
+    if (p.tri == 1 && c.n0 >= c.m0 + P3_BM) c.nt = 0;          // tile above the diagonal: nothing to do
+}
+
+// advance to the next tile that has work; c.valid = false when the list is exhausted
+__device__ __forceinline__ void tile_next(const GemmP& p, int total, int tiles_per_z, TileCur& c) {
+    for (;;) {
+        ++c.k;
+        const int w = (int)blockIdx.x + c.k * (int)gridDim.x;
+        if (w >= total) { c.valid = false; c.nt = 0; return; }
+        tile_decode(p, total, tiles_per_z, w, c);
+        if (c.nt > 0) { c.valid = true; return; }
+    }
+}
+
+template <bool AKC, bool BKC, typename TOUT>
+__global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmP p, int total, int tiles_per_z) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * P3_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const bool grp_b = wid >= 4;
+    const int64_t astep = AKC ? BK : (int64_t)BK * p.lda;
+    const int64_t bstep = BKC ? BK : (int64_t)BK * p.ldb;
+
+    uint32_t ba[4], bb[4];
+    frag_bases<AKC, 2 * P3_BM>(wm * 64, lane, ba);
+    frag_bases<BKC, 2 * P3_BN>(wn * 64, lane, bb);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+
+    // ---- DMA cursor (runs two K-tiles ahead of the compute cursor) ------------------------------------------
+    TileCur dc;
+    dc.k = -1; dc.valid = true; dc.nt = 0;
+    int d_rem = 0;                       // K-tiles of dc's tile not yet issued
+    const bf16_t* ga[4];
+    const bf16_t* gb[2];
+    int d_stage = 0;
+    auto dma_fetch_tile = [&]() {        // move dc to the next tile with work and set up its piece pointers
+        tile_next(p, total, tiles_per_z, dc);
+        if (!dc.valid) return;
+        const int64_t bo = dc.z / p.batch_i, bi = dc.z % p.batch_i;
+        const bf16_t* A = reinterpret_cast<const bf16_t*>(p.a) + bo * p.sa_o + bi * p.sa_i;
+        const bf16_t* B = reinterpret_cast<const bf16_t*>(p.b) + bo * p.sb_o + bi * p.sb_i;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            ga[q] = piece_src<AKC, 2 * P3_BM>(A, p.lda, dc.m0, p.M, wid + 8 * q, lane) + (int64_t)dc.t0 * astep;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            gb[q] = piece_src<BKC, 2 * P3_BN>(B, p.ldb, dc.n0, p.N, wid + 8 * q, lane) + (int64_t)dc.t0 * bstep;
+        d_rem = dc.nt;
+    };
+    // returns false when there is nothing left to issue.  part 0: first half (3 A pieces), 1..3: one piece each,
+    // 4: all six pieces
+    bool d_have = false;                 // a K-tile is selected for issue (its first half may already be out)
+    auto dma_select = [&]() -> bool {    // make sure a K-tile is selected
+        if (d_have) return true;
+        while (d_rem == 0) {
+            if (!dc.valid) return false;
+            dma_fetch_tile();
+            if (!dc.valid) return false;
+        }
+        d_have = true;
+        return true;
+    };
+    auto dma_issue_h1 = [&]() {
+        char* sa = smem + d_stage * P3_STAGE + wid * 1024;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { glds16(ga[q], sa + q * 8192); ga[q] += astep; }
+    };
+    auto dma_issue_h2 = [&](int which) {
+        char* sa = smem + d_stage * P3_STAGE + wid * 1024;
+        if (which == 0) { glds16(ga[3], sa + 3 * 8192); ga[3] += astep; }
+        else { glds16(gb[which - 1], sa + P3_A_BYTES + (which - 1) * 8192); gb[which - 1] += bstep; }
+    };
+    auto dma_done_tile = [&]() {         // the selected K-tile is completely issued
+        d_have = false;
+        --d_rem;
+        d_stage = d_stage == 2 ? 0 : d_stage + 1;
+    };
+    auto dma_issue_full = [&]() {
+        dma_issue_h1();
+        dma_issue_h2(0); dma_issue_h2(1); dma_issue_h2(2);
+        dma_done_tile();
+    };
+
+    // ---- compute cursor ---------------------------------------------------------------------------------------
+    TileCur cc;
+    cc.k = -1; cc.valid = true; cc.nt = 0;
+    tile_next(p, total, tiles_per_z, cc);
+    if (!cc.valid) return;               // this workgroup has no work at all (uniform over the workgroup)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: K-tiles g = 0 and g = 1 completely issued
+    int issued = 0;
+    if (dma_select()) { dma_issue_full(); ++issued; }
+    if (dma_select()) { dma_issue_full(); ++issued; }
+    if (issued == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (grp_b) __builtin_amdgcn_s_barrier();
+
+    int s_cur = 0;
+    int t = 0;                           // K-tile index inside the compute tile
+    for (;;) {
+        // ---------------- H1(g) ----------------
+        const bool more2 = dma_select();           // is there a K-tile g+2 ?
+        if (more2) dma_issue_h1();
+        const uint32_t sao = lds_base + (uint32_t)(s_cur * P3_STAGE);
+        const uint32_t sbo = sao + P3_A_BYTES;
+        bf16x8 fa[2][4], fb[2][4];
+        fa[0][0] = frag_read<AKC, 2 * P3_BM, 0, 0>(ba, sao);
+        fa[0][1] = frag_read<AKC, 2 * P3_BM, 0, 1>(ba, sao);
+        fa[0][2] = frag_read<AKC, 2 * P3_BM, 0, 2>(ba, sao);
+        fa[0][3] = frag_read<AKC, 2 * P3_BM, 0, 3>(ba, sao);
+        fb[0][0] = frag_read<BKC, 2 * P3_BN, 0, 0>(bb, sbo);
+        fb[0][1] = frag_read<BKC, 2 * P3_BN, 0, 1>(bb, sbo);
+        fb[0][2] = frag_read<BKC, 2 * P3_BN, 0, 2>(bb, sbo);
+        fb[0][3] = frag_read<BKC, 2 * P3_BN, 0, 3>(bb, sbo);
+        fa[1][0] = frag_read<AKC, 2 * P3_BM, 1, 0>(ba, sao);
+        fa[1][1] = frag_read<AKC, 2 * P3_BM, 1, 1>(ba, sao);
+        fa[1][2] = frag_read<AKC, 2 * P3_BM, 1, 2>(ba, sao);
+        fa[1][3] = frag_read<AKC, 2 * P3_BM, 1, 3>(ba, sao);
+        fb[1][0] = frag_read<BKC, 2 * P3_BN, 1, 0>(bb, sbo);
+        fb[1][1] = frag_read<BKC, 2 * P3_BN, 1, 1>(bb, sbo);
+        fb[1][2] = frag_read<BKC, 2 * P3_BN, 1, 2>(bb, sbo);
+        fb[1][3] = frag_read<BKC, 2 * P3_BN, 1, 3>(bb, sbo);
+        // K-tile g+1 (if it exists) was issued completely one interval pair ago; only g+2's first half is newer.
+        // (epilogue stores issued in between only make the counted wait stricter: VMEM ops retire in order)
+        if (more2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---------------- H2(g) ----------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[ks][i], acc[i][j], 0, 0, 0);
+                if (more2 && ks * 4 + i == 1) dma_issue_h2(0);
+                if (more2 && ks * 4 + i == 3) dma_issue_h2(1);
+                if (more2 && ks * 4 + i == 5) dma_issue_h2(2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        if (more2) dma_done_tile();
+        s_cur = s_cur == 2 ? 0 : s_cur + 1;
+        ++t;
+        bool finished = false;
+        if (t == cc.nt) {
+            // ---- epilogue of the compute tile (its successor's K-tiles are already streaming in) ----
+            const int64_t bo = cc.z / p.batch_i, bi = cc.z % p.batch_i;
+            TOUT* C = reinterpret_cast<TOUT*>(p.c) + bo * p.sc_o + bi * p.sc_i;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t m = cc.m0 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t n = cc.n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+                    if (m < p.M && n < p.N) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = acc[i][j][r] * p.alpha;
+                            if (p.bias) v[r] += p.bias[n + r];
+                        }
+                        TOUT* dst = C + m * p.ldc + n;
+                        if constexpr (sizeof(TOUT) == 4) {
+                            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                        } else {
+                            typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+                            *reinterpret_cast<bf4*>(dst) = bf4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                        }
+                    }
+                    acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            t = 0;
+            tile_next(p, total, tiles_per_z, cc);
+            finished = !cc.valid;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (finished) break;
+    }
+    if (!grp_b) __builtin_amdgcn_s_barrier();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // exact f32 path
 // ---------------------------------------------------------------------------------------------------
 constexpr int FM = 64, FN = 64, FK = 16;
@@ -677,6 +902,37 @@ extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias
             p.tiles_n = (int)tn3;
             p.tiles_m = (int)tm3;
             dim3 grid3((unsigned)(tm3 * tn3), 1, (unsigned)(batch_o * batch_i));
+            // persistent tile loop: wins where the per-tile pipeline fill dominates (short K, batched attention
+            // problems); the plain kernel's leaner main loop wins on the long-K linears (measured, tools/ab_gemm.py)
+            const int persist = dbg_env_i("OQ_GEMM_PERSIST", 2);
+            if (persist == 1 || (persist == 2 && (K <= 256 || batch_o * batch_i > 1))) {
+                const int tiles_per_z = (int)(tm3 * tn3);
+                const int64_t total64 = (int64_t)tiles_per_z * batch_o * batch_i;
+                OQ_CHECK_ARG(total64 < (1ll << 30), "oq_gemm: too many tiles");
+                const int total = (int)total64;
+                static int n_cu = 0;
+                if (n_cu == 0) {
+                    int dev = 0;
+                    hipDeviceProp_t prop;
+                    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                        n_cu = prop.multiProcessorCount;
+                    if (n_cu <= 0) n_cu = 256;
+                }
+                const int gridp = total < n_cu ? total : n_cu;     // one 144 KiB-LDS workgroup per CU
+#define LAUNCH_PP(AK, BK_, T) hipLaunchKernelGGL((gemm_bf16_pp_kernel<AK, BK_, T>), dim3(gridp), dim3(512), 0, st, p, total, tiles_per_z)
+                switch (key) {
+                    case 0: LAUNCH_PP(false, false, bf16_t); break;
+                    case 1: LAUNCH_PP(false, false, float); break;
+                    case 2: LAUNCH_PP(false, true, bf16_t); break;
+                    case 3: LAUNCH_PP(false, true, float); break;
+                    case 4: LAUNCH_PP(true, false, bf16_t); break;
+                    case 5: LAUNCH_PP(true, false, float); break;
+                    case 6: LAUNCH_PP(true, true, bf16_t); break;
+                    case 7: LAUNCH_PP(true, true, float); break;
+                }
+                OQ_CHECK_LAUNCH("oq_gemm(pp)");
+                return OQ_OK;
+            }
             const bool stagger = dbg_env_i("OQ_GEMM_STAGGER", 1) != 0;
             const bool split = dbg_env_i("OQ_GEMM_SPLIT", 1) != 0;
 #define LAUNCH_P3(AK, BK_, T)                                                                                          \
