@@ -82,3 +82,37 @@ def test_trajectory_bf16_loss_curve():
     ref = g["losses"]
     assert np.isfinite(losses).all()
     assert abs(np.mean(losses) - ref.mean()) / ref.mean() < 0.1
+
+
+def test_sharded_engine_single_rank_matches_sequential():
+    """omniquant_amd.parallel with the HIP callables (world_size 1, RCCL backend): partition + teacher pre-pass +
+    calibrate + gather must reproduce the plain sequential engine (same golden trajectory)."""
+    import torch.distributed as dist
+    from omniquant_amd.parallel import calibrate_sharded, hip_callables
+    from omniquant_amd.synthetic import make_layer
+    g, m = load_golden("g4_traj_llama_w3a16g32_lwc.npz")
+    cfg, args = make_cfg(m), make_args(m)
+    layers = []
+    for i in range(m["n_layers"]):
+        w = {k[len(f"w{i}."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith(f"w{i}.")}
+        layers.append(make_layer(cfg, weights=w, device=DEV))
+    pos = torch.from_numpy(g["position_ids"]).to(DEV)
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        teacher, calib = hip_callables(layers, cfg, args, T(g["mask"], DEV), pos, compute_dtype=torch.float32)
+        merged, (lo, hi) = calibrate_sharded(m["n_layers"], T(g["inps"], DEV), teacher, calib)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert (lo, hi) == (0, m["n_layers"]) and sorted(merged.keys()) == list(range(m["n_layers"]))
+    for i in range(m["n_layers"]):
+        for k in [k for k in g if k.startswith(f"omni.{i}.")]:
+            n = k[len(f"omni.{i}."):]
+            ref = g[k].astype(np.float64)
+            got = merged[i][n].double().numpy()
+            assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6) + 1e-3, (i, n)
