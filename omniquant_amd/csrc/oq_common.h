@@ -133,6 +133,8 @@ __device__ __forceinline__ float ld1(const T* p) { return (float)*p; }
 template <typename T>
 __device__ __forceinline__ void st1(T* p, float v) { *p = (T)v; }
 
+__device__ __forceinline__ float vmax(float a, float b);
+__device__ __forceinline__ float vmin(float a, float b);
 // ---- wave-level reductions (width = power of two <= 64, lanes grouped contiguously) -------------
 // Butterfly on DPP (quad_perm / row_half_mirror / row_mirror: 1 VALU op each, no LDS crossbar), ds_swizzle for the
 // 16<->16 step and two v_readlane for the 32<->32 step.  Every lane of a group ends with the group's result.
@@ -165,13 +167,26 @@ __device__ __forceinline__ float dpp_f(float v, const int ctrl_sel) {
     }
 __device__ __forceinline__ float oq_addf(float a, float b) { return a + b; }
 OQ_WAVE_REDUCE(wave_sum, oq_addf)
-OQ_WAVE_REDUCE(wave_max, fmaxf)
-OQ_WAVE_REDUCE(wave_min, fminf)
+OQ_WAVE_REDUCE(wave_max, vmax)
+OQ_WAVE_REDUCE(wave_min, vmin)
 // NaN-propagating variants: torch.amax/amin propagate NaN, fmaxf does not.
 __device__ __forceinline__ float nmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
 __device__ __forceinline__ float nmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Raw v_max_f32 / v_min_f32: fmaxf/fminf compile to canonicalise + max (3 VALU ops); the single instruction returns
+// the non-NaN operand exactly like fmaxf (IEEE maxNum) and is all the hot loops need.
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 static inline int oq_dtype_size(int dt) { return dt == OQ_F32 ? 4 : 2; }
 static inline bool oq_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -222,8 +222,8 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
             if (valid[j]) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    hi[j] = fmaxf(hi[j], x[j][i]);
-                    lo[j] = fminf(lo[j], x[j][i]);
+                    hi[j] = vmax(hi[j], x[j][i]);
+                    lo[j] = vmin(lo[j], x[j][i]);
                     bad[j] = (x[j][i] != x[j][i]) ? 1.f : bad[j];
                 }
             }
@@ -249,21 +249,27 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
             for (int j = 0; j < CH; ++j) { hi[j] = v[0]; lo[j] = v[1]; bad[j] = v[2]; }
         }
         // ---- quantise ---------------------------------------------------------------------------
+        QP q;
+        float inv_s = 0.f;
+        q.s = 1.f; q.z = 0.f; q.su = q.sl = 1.f; q.hi = q.lo = 0.f;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (!valid[j]) continue;
             const int64_t sidx = r * nseg + segi[j];
             float h = hi[j], l = lo[j];
             if (bad[j] != 0.f) { h = NAN; l = NAN; }
-            const QP q = make_qp(h, l, lwc, cup[j], clow[j], p.nbits, p.symmetric);
+            // whole-row segments: scale / zero-point / 1/scale are the same for every chunk of the thread -> once
+            if (small || j == 0) {
+                q = make_qp(h, l, lwc, cup[j], clow[j], p.nbits, p.symmetric);
+                inv_s = 1.f / q.s;
+            }
             float yv[8];
-            const float inv_s = 1.f / q.s;
             if (q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad[j] == 0.f) {
                 // regular segment (finite non-zero scale, no NaN): no special values can appear below
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float tq;
-                    const float v = fminf(fmaxf(rne_div(x[j][i], q.s, inv_s, &tq) + q.z, 0.f), Q);
+                    const float v = vmin(vmax(rne_div(x[j][i], q.s, inv_s, &tq) + q.z, 0.f), Q);
                     yv[i] = (v - q.z) * q.s;
                 }
             } else {
@@ -395,7 +401,7 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
             lo[j] = INFINITY;
             if (valid[j]) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { hi[j] = fmaxf(hi[j], x[j][i]); lo[j] = fminf(lo[j], x[j][i]); }
+                for (int i = 0; i < 8; ++i) { hi[j] = vmax(hi[j], x[j][i]); lo[j] = vmin(lo[j], x[j][i]); }
             }
         }
         if (small) {
@@ -417,14 +423,19 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
         for (int j = 0; j < CH; ++j) {
             gs[j] = 0.f; nhi[j] = 0.f; nlo[j] = 0.f; inv_s[j] = 0.f;
             if (valid[j]) {
-                qp[j] = make_qp(hi[j], lo[j], lwc, cup[j], clow[j], p.nbits, p.symmetric);
-                inv_s[j] = 1.f / qp[j].s;
+                if (small || j == 0) {
+                    qp[j] = make_qp(hi[j], lo[j], lwc, cup[j], clow[j], p.nbits, p.symmetric);
+                    inv_s[j] = 1.f / qp[j].s;
+                } else {
+                    qp[j] = qp[0];        // whole-row segment: every chunk shares the row's parameters
+                    inv_s[j] = inv_s[0];
+                }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float tq = x[j][i] * inv_s[j];
                     const float v = rne_ste(tq) + qp[j].z;
                     const bool in = (v >= 0.f) && (v <= Q);
-                    const float qv = fminf(fmaxf(v, 0.f), Q);
+                    const float qv = vmin(vmax(v, 0.f), Q);
                     gs[j] += G[j][i] * ((qv - qp[j].z) - (in ? tq : 0.f));
                     nhi[j] += (x[j][i] == hi[j]) ? 1.f : 0.f;
                     nlo[j] += (x[j][i] == lo[j]) ? 1.f : 0.f;
