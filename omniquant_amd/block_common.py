@@ -54,6 +54,29 @@ class QuantBlockMixin:
             cache[id(t)] = (key, t.detach().float().contiguous(), t)     # keep `t` alive so id() stays unique
         return cache[id(t)][1]
 
+    # ---- second HIP stream for the weight path -----------------------------------------------------------------
+    # The weight fake-quant kernels (HBM/VALU-bound, no LDS) and their backward depend only on the learnables and on
+    # dL/dW, not on the activations, so they can run beside the MFMA-bound GEMMs of the activation path.  When
+    # `_fq_stream` is set (StepRunner does it), they are enqueued on that stream; each QuantLinear waits for its
+    # own weight's event right before its GEMM.  Autograd runs every backward node on the stream of its forward, so
+    # the fake-quant BACKWARD kernels land on the side stream as well and overlap the remaining dgrad/wgrad GEMMs.
+    def _weight_stream(self):
+        """(stream, forked): the side stream when one is configured, else the current stream."""
+        st = self.__dict__.get("_fq_stream")
+        if st is None:
+            return torch.cuda.current_stream(), False
+        return st, True
+
+    def _publish(self, mod, weight, bias, side, forked):
+        mod.temp_weight, mod.temp_bias = weight, bias
+        mod.use_temporary_parameter = True
+        if forked:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            mod._temp_ready = ev
+        else:
+            mod._temp_ready = None
+
     def _let_temporaries(self, out_dtype):
         """Fused LET path: 6 fused transform+fake-quant kernels (one per smoothed linear) + ONE vector kernel for
         every norm weight/bias and projection bias.  Returns {module: (temp_weight, temp_bias)} and the norm temps."""
@@ -84,20 +107,28 @@ class QuantBlockMixin:
         vector kernel (reference: ~25 eager passes per matrix, models/int_llama_layer.py:279-307)."""
         nm = self._let_names()
         dt = self.compute_dtype
+        main = torch.cuda.current_stream()
+        side, forked = self._weight_stream()
         if self.let:
             self._truncate_scales()
-            wq, bias, t1, t2 = self._let_temporaries(dt)
+            if forked:
+                side.wait_stream(main)      # parameters were updated (AdamW / truncate) on the main stream
+            with torch.cuda.stream(side):
+                wq, bias, t1, t2 = self._let_temporaries(dt)
+                for mod in wq:
+                    self._publish(mod, wq[mod], bias[mod], side, forked)
+            if forked:
+                main.wait_stream(side)      # norm weights/biases are needed at the very start of the block
+                # (the per-linear events above are then already satisfied; LWC-only blocks below overlap more)
             for ln, (tw, tb) in ((nm["ln1"], t1), (nm["ln2"], t2)):
                 ln.temp_weight, ln.temp_bias = tw, tb
                 ln.use_temporary_parameter = True
-            for mod in wq:
-                mod.temp_weight, mod.temp_bias = wq[mod], bias[mod]
-                mod.use_temporary_parameter = True
         else:
-            for mod in self._quant_linears():
-                mod.temp_weight = mod.weight_quantizer.quantize(mod.weight, out_dtype=dt)
-                mod.temp_bias = mod.bias
-                mod.use_temporary_parameter = True
+            if forked:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for mod in self._quant_linears():
+                    self._publish(mod, mod.weight_quantizer.quantize(mod.weight, out_dtype=dt), mod.bias, side, forked)
 
     def clear_temp_variable(self):
         nm = self._let_names()

@@ -110,6 +110,10 @@ class StepRunner:
         self.graph = None
         self.use_graph = use_graph
         self.steps = 0
+        # opt-in: on ROCm 7.2 a hipGraph replays its parallel branches on ONE hardware queue (measured: zero overlap in
+        # the rocprofv3 trace), so the second stream only pays off for un-captured (eager) stepping
+        if os.environ.get("OQ_WEIGHT_STREAM", "0") != "0":
+            qlayer.__dict__["_fq_stream"] = torch.cuda.Stream(device=dev)   # see QuantBlockMixin._weight_stream
 
     def _forward(self):
         if self.is_llama:

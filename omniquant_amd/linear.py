@@ -65,6 +65,13 @@ class QuantLinear(nn.Module):
     def forward(self, input: torch.Tensor, input_is_quantized: bool = False):
         if self.use_temporary_parameter:
             weight, bias = self.temp_weight, self.temp_bias
+            ev = self.__dict__.get("_temp_ready")
+            if ev is not None:                      # temp weight was produced on the block's weight stream
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                weight.record_stream(cur)
+                if bias is not None:
+                    bias.record_stream(cur)
         elif self.use_weight_quant:
             weight, bias = self.weight_quantizer.quantize(self.weight, out_dtype=input.dtype), self.bias
         else:
