@@ -95,15 +95,21 @@ def gemm_roofline(runner, quant_inps, fp_inps, cfg, n_prof=3):
     """Per-launch duration of the MFMA GEMM kernel, measured with HIP events on the launch stream while the real
     sample-step runs eagerly (same data, same cache state as the timed loop)."""
     from omniquant_amd import ops
+    import inspect
     rec = []
     orig = ops.gemm
+    sig = inspect.signature(orig)
 
     def timed(a, b, c, M, N, K, *rest, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(torch.cuda.current_stream())
         orig(a, b, c, M, N, K, *rest, **kw)
         e1.record(torch.cuda.current_stream())
-        rec.append((e0, e1, 2.0 * M * N * K * kw.get("batch_o", 1) * kw.get("batch_i", 1), (M, N, K)))
+        ba = sig.bind(a, b, c, M, N, K, *rest, **kw)
+        ba.apply_defaults()
+        g = ba.arguments
+        nb = g["batch_o"] * g["batch_i"]
+        rec.append((e0, e1, 2.0 * M * N * K * nb, (M, N, K, int(g["a_kc"]), int(g["b_kc"]), nb, int(g["tri"]))))
 
     runner.use_graph = False
     ops.gemm = timed
@@ -115,13 +121,36 @@ def gemm_roofline(runner, quant_inps, fp_inps, cfg, n_prof=3):
         ops.gemm = orig
         runner.use_graph = True
     H = cfg.hidden_size
-    lin = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, (M, N, K) in rec if min(M, N, K) >= 1024 or (M * N * K >= 2048 * H * H)]
+    lin = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, sh in rec
+           if sh[5] == 1 and (min(sh[:3]) >= 1024 or (sh[0] * sh[1] * sh[2] >= 2048 * H * H))]
+    if os.environ.get("OQ_BENCH_SHAPES"):
+        import collections
+        by = collections.OrderedDict()
+        for e0, e1, fl, sh in rec:
+            a = by.setdefault(sh, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += fl
+        for sh, (n, t, fl) in by.items():
+            tri = {0: 1.0, 1: 0.5, 2: 0.5, 3: 0.5}.get(sh[6], 1.0)
+            print(f"[gemm] M={sh[0]:6d} N={sh[1]:6d} K={sh[2]:6d} a_kc={sh[3]} b_kc={sh[4]} batch={sh[5]:3d} tri={sh[6]} "
+                  f"n/step={n // n_prof:2d} avg={1e6 * t / n:8.1f} us  {fl * tri / t / 1e12:7.1f} TF/s", file=sys.stderr)
     tot_t = sum(t for t, _ in lin)
     tot_f = sum(f for _, f in lin)
     n = len(lin)
     all_t = sum(e0.elapsed_time(e1) * 1e-3 for e0, e1, _, _ in rec)
     return dict(launches_per_step=n // n_prof, avg_launch_ms=1e3 * tot_t / max(n, 1), tflops=tot_f / tot_t / 1e12,
                 gemm_ms_per_step=1e3 * all_t / n_prof, linear_gemm_ms_per_step=1e3 * tot_t / n_prof)
+
+
+def pmc_traffic(name):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
+    WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); counters
+    cannot be read from inside this process, so the number comes from profiles/ and is null for an unprofiled config."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_gemm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(name, {}).get("bytes_per_launch")
+    except OSError:
+        return None
 
 
 def cpu_baseline(name, n_steps=1):
@@ -223,7 +252,7 @@ def main():
                        "linear_tflop_per_step": flops / 1e12},
             "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (fprop+dgrad+wgrad of the fake-quant linears)",
                          "achieved": roof["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "frac": roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(a.config),
                          "avg_launch_ms": roof["avg_launch_ms"], "launches_per_step": roof["launches_per_step"],
                          "linear_gemm_ms_per_step": roof["linear_gemm_ms_per_step"],
                          "all_gemm_ms_per_step": roof["gemm_ms_per_step"]},

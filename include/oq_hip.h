@@ -123,6 +123,19 @@ int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols
                    int64_t mask_rows, int causal, void* stream);
 int oq_softmax_bwd(const void* p, const void* gp, void* gs, int dtype, int64_t rows, int64_t cols, float alpha,
                    int causal, void* stream);
+/* ---- fused causal attention (models/int_llama_layer.py:143-163 and its autograd; bf16, head_dim 128, exact
+ *      causal mask, T == 128 or T % 256 == 0 -- oq_attn_supported() says whether a problem qualifies; everything else keeps using
+ *      oq_gemm + oq_softmax_*).  q, o, go [bs,T,nh,hd]; k, v [bs,T,nkv,hd] (q/k/v already fake-quantised by the caller,
+ *      as quant_x1/quant_x2 do in the reference); lse [bs,nh,T] f32 (log2 domain) is written by fwd and read by bwd.
+ *      bwd writes gk, gv [bs,T,nh,hd] (per q-head: the caller sums GQA groups), dsum [bs,nh,T] f32 scratch and
+ *      ds_t = dS^T [bs,nh,T(key),T(query)] bf16 with zeros above the diagonal inside each 256-block, so that
+ *      dQ = dS K is one oq_gemm(a=ds_t, a_kc=0, b=k, b_kc=0, tri_mode=2).  No atomics: results are deterministic. */
+int64_t oq_attn_supported(int dtype, int64_t T, int hd, int causal);
+int oq_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int64_t bs, int64_t T,
+                int nh, int nkv, int hd, float scale, int causal, void* stream);
+int oq_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* go, const float* lse,
+                float* dsum, void* ds_t, void* gk, void* gv, int dtype, int64_t bs, int64_t T, int nh, int nkv, int hd,
+                float scale, int causal, void* stream);
 /* loss[0] += mean((out-t1)^2) (+ mean((out-t2)^2) if t2); g = dloss/dout * gscale.  loss zeroed by caller. */
 int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, int dtype, int64_t n, float gscale,
                    float* loss, void* g, void* stream);

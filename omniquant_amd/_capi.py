@@ -34,6 +34,8 @@ SIGNATURES = {
     "oq_relu_bwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_softmax_fwd": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _i64, _i32, _vp],
     "oq_softmax_bwd": [_vp, _vp, _vp, _i32, _i64, _i64, _f32, _i32, _vp],
+    "oq_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
+    "oq_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "oq_mse_fwd_bwd": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],
     "oq_add": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_scale": [_vp, _f32, _vp, _i32, _i64, _vp],
@@ -46,7 +48,8 @@ SIGNATURES = {
 }
 
 # functions returning a size instead of an error code
-SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64]}
+SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64],
+              "oq_attn_supported": [_i32, _i64, _i32, _i32]}
 
 _lib = None
 

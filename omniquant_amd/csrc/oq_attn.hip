@@ -1,0 +1,422 @@
+// Fused causal attention for the calibration step (gfx950), bf16, head_dim 128.
+//
+// Replaces, for the exact-causal-mask case, the chain at models/int_llama_layer.py:143-163
+//     qkt_matmul(q, k^T) / sqrt(hd)  ->  + mask, max(finfo.min)  ->  softmax(fp32)  ->  pv_matmul(p, v)
+// and its autograd, without ever writing the [heads, T, T] score / probability tensors:
+//   attn_fwd_kernel      O = softmax(scale * Q K^T) V, online softmax in f32, also stores the row log-sum-exp
+//   attn_bwd_prep_kernel D[q] = sum_d O[q,d] dO[q,d]
+//   attn_bwd_kernel      one workgroup per 64-key tile: recomputes P from (Q, K, lse), accumulates dK and dV in
+//                        registers over the query tiles at/below the diagonal and writes dS^T (bf16, [key][query]);
+//                        dQ = dS K is then one causal GEMM (oq_gemm, tri_mode 2) -- no atomics, deterministic.
+// q/k/v fake-quant (the 4-bit head-wise activations of W4A4) happens BEFORE these kernels exactly as in the
+// reference; the p-quantiser is the identity at the reference's default 16 bits (the caller falls back to the
+// unfused kernels otherwise).
+//
+// Layout: q, o, dO, dQ [bs, T, nh, 128]; k, v [bs, T, nkv, 128]; dK, dV [bs, T, nh, 128] (per q-head; the caller
+// reduces GQA groups).  LDS tiles are [64 rows][128 d] bf16 (256-B rows) with the 16-B chunk index XOR-swizzled by
+// s(row) = ((row&7)<<1)|((row>>3)&1): conflict-free for both ds_read_b128 row fragments (16 rows x one chunk) and
+// ds_read_b64_tr_b16 transposed fragments (8 rows x 32 B).
+//
+// MFMA operand trick (no cross-lane shuffles between the two GEMMs of a tile): the first product is computed so that
+// the softmax'd block comes out of the accumulator with the contraction index of the SECOND product along the
+// register index i (C row = 4*(lane>>4)+i); two such blocks (rows 0-15 and 16-31 of a 32-chunk) packed in-lane give a
+// 16x16x32 operand whose k-slot 8g+i <-> row 4g+i and 8g+4+i <-> row 16+4g+i; the other operand is read from LDS with
+// the same permutation (two transposed reads, rows 4g+q and 16+4g+q).
+#include "oq_common.h"
+
+namespace {
+
+constexpr int HD = 128;
+constexpr int TILE = 64 * HD * 2;   // 16 KiB
+
+struct AttnP {
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* v;
+    bf16_t* o;
+    float* lse;            // [bs, nh, T] log2-domain log-sum-exp of scale*log2e*S
+    const bf16_t* go;
+    const float* dsum;     // [bs, nh, T]
+    bf16_t* gk;
+    bf16_t* gv;
+    bf16_t* dst;           // dS^T [bs, nh, T(key), T(query)]
+    int64_t T;
+    int nh, nkv;
+    float scale, scale_log2;
+};
+
+__device__ __forceinline__ int swz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+
+__device__ __forceinline__ void tile_gload(const bf16_t* base, int64_t ld, int tid, u32x4 (&r)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        r[p] = *reinterpret_cast<const u32x4*>(base + (int64_t)((tid >> 4) + 16 * p) * ld + (tid & 15) * 8);
+}
+
+__device__ __forceinline__ void tile_sstore(char* lds, int tid, const u32x4 (&r)[4]) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = (tid >> 4) + 16 * p, c = tid & 15;
+        *reinterpret_cast<u32x4*>(lds + row * 256 + ((c ^ swz(row)) << 4)) = r[p];
+    }
+}
+
+// k-contiguous fragment: lane's 8 bf16 = X[row0 + (lane&15)][32*ks + 8*(lane>>4) .. +8]
+__device__ __forceinline__ bf16x8 frag_row(const char* lds, int row0, int ks, int lane) {
+    const int row = row0 + (lane & 15), c = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(lds + row * 256 + ((c ^ swz(row)) << 4));
+}
+
+// transposed fragment with the permuted k-slots: element j<4 = X[r0 + 4g + j][col0 + (lane&15)],
+// element 4+j = X[r0 + 16 + 4g + j][col0 + (lane&15)]   (g = lane>>4, col0 a multiple of 16)
+__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int r0, int col0, int lane) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s4;
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int ra = r0 + 4 * g + qq, rb = ra + 16;
+    const int c = (col0 >> 3) + (pp >> 1), sub = (pp & 1) * 8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + ra * 256 + ((c ^ swz(ra)) << 4) + sub));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4*)(lds + rb * 256 + ((c ^ swz(rb)) << 4) + sub));
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = (bf16_t)a[i]; r[4 + i] = (bf16_t)b[i]; }
+    return r;
+}
+
+__device__ __forceinline__ float xor16(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
+__device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------
+// forward: workgroup = 128 queries of one head (4 waves x 32 queries), key/value tiles of 64 through LDS
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [stage][K | V]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;          // heaviest (longest key range) tiles first
+    const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.nh / p.nkv);
+    const int64_t ldq = (int64_t)p.nh * HD, ldk = (int64_t)p.nkv * HD;
+    const int q0 = qt * 128, qw0 = q0 + 32 * w;
+    const bf16_t* qp = p.q + ((int64_t)b * p.T) * ldq + (int64_t)h * HD;
+    const bf16_t* kp = p.k + ((int64_t)b * p.T) * ldk + (int64_t)hk * HD;
+    const bf16_t* vp = p.v + ((int64_t)b * p.T) * ldk + (int64_t)hk * HD;
+
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[qb][ks] = *reinterpret_cast<const bf16x8*>(qp + (int64_t)(qw0 + 16 * qb + c) * ldq + 32 * ks + 8 * g);
+
+    f32x4 o[2][8];
+    float m[2], l[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        m[qb] = -INFINITY;
+        l[qb] = 0.f;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) o[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int ntiles = 2 * qt + 2;
+    u32x4 rk[4], rv[4];
+    tile_gload(kp, ldk, tid, rk);
+    tile_gload(vp, ldk, tid, rv);
+    tile_sstore(smem, tid, rk);
+    tile_sstore(smem + TILE, tid, rv);
+    __syncthreads();
+    for (int j = 0; j < ntiles; ++j) {
+        const int cur = j & 1;
+        if (j + 1 < ntiles) {
+            tile_gload(kp + (int64_t)(64 * (j + 1)) * ldk, ldk, tid, rk);
+            tile_gload(vp + (int64_t)(64 * (j + 1)) * ldk, ldk, tid, rv);
+        }
+        const char* Ks = smem + cur * 2 * TILE;
+        const char* Vs = Ks + TILE;
+        const int kpos0 = 64 * j;
+        if (kpos0 <= qw0 + 31) {     // wave-uniform: this wave has at least one unmasked (query, key) pair in the tile
+            f32x4 st[4][2];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                st[kb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+                st[kb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = frag_row(Ks, 16 * kb, ks, lane);
+                    st[kb][0] = MFMA(kf, qf[0][ks], st[kb][0]);     // S^T block: row = key 16kb+4g+i, col = query c
+                    st[kb][1] = MFMA(kf, qf[1][ks], st[kb][1]);
+                }
+            }
+            const bool diag = kpos0 + 63 > qw0;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const int qi = qw0 + 16 * qb + c;
+                float mx = m[qb];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float s = st[kb][qb][i] * p.scale_log2;
+                        if (diag && kpos0 + 16 * kb + 4 * g + i > qi) s = -INFINITY;
+                        st[kb][qb][i] = s;
+                        mx = vmax(mx, s);
+                    }
+                mx = vmax(mx, xor16(mx));
+                mx = vmax(mx, xor32(mx));
+                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mx);
+                m[qb] = mx;
+                float ls = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float pv = __builtin_amdgcn_exp2f(st[kb][qb][i] - mx);
+                        st[kb][qb][i] = pv;
+                        ls += pv;
+                    }
+                l[qb] = l[qb] * alpha + ls;
+#pragma unroll
+                for (int db = 0; db < 8; ++db)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[qb][db][i] *= alpha;
+            }
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const bf16x8 p0 = pack8(st[2 * kc][0], st[2 * kc + 1][0]);
+                const bf16x8 p1 = pack8(st[2 * kc][1], st[2 * kc + 1][1]);
+#pragma unroll
+                for (int db = 0; db < 8; ++db) {
+                    const bf16x8 vf = frag_tr(Vs, 32 * kc, 16 * db, lane);   // V^T: row = d 16db+(lane&15)
+                    o[0][db] = MFMA(vf, p0, o[0][db]);                        // O^T block: row = d 16db+4g+i, col = query
+                    o[1][db] = MFMA(vf, p1, o[1][db]);
+                }
+            }
+        }
+        if (j + 1 < ntiles) {
+            tile_sstore(smem + (cur ^ 1) * 2 * TILE, tid, rk);
+            tile_sstore(smem + (cur ^ 1) * 2 * TILE + TILE, tid, rv);
+        }
+        __syncthreads();
+    }
+    bf16_t* op = p.o + ((int64_t)b * p.T) * ldq + (int64_t)h * HD;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float ls = l[qb];
+        ls += xor16(ls);
+        ls += xor32(ls);
+        const float inv = 1.0f / ls;
+        const int qi = qw0 + 16 * qb + c;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+            bf4 ov;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ov[i] = (bf16_t)(o[qb][db][i] * inv);
+            *reinterpret_cast<bf4*>(op + (int64_t)qi * ldq + 16 * db + 4 * g) = ov;
+        }
+        if (g == 0) p.lse[((int64_t)b * p.nh + h) * p.T + qi] = m[qb] + __builtin_amdgcn_logf(ls);   // v_log_f32 = log2
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// D[b,h,q] = sum_d O[q,h,d] * dO[q,h,d]   (one 16-lane group per (q,h) row of 128)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) attn_bwd_prep_kernel(AttnP p, int64_t nrows) {
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);    // row index over [bs*T*nh]
+    if (r >= nrows) return;
+    const int c = threadIdx.x & 15;
+    float a[8], bq[8];
+    Vec8<bf16_t>::load(p.o + r * HD + c * 8, a);
+    Vec8<bf16_t>::load(p.go + r * HD + c * 8, bq);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s = fmaf(a[i], bq[i], s);
+    s = wave_sum(s, 16);
+    if (c == 0) {
+        const int64_t bt = r / p.nh;          // b*T + q
+        const int h = (int)(r - bt * p.nh);
+        const int64_t b = bt / p.T, q = bt - b * p.T;
+        const_cast<float*>(p.dsum)[(b * p.nh + h) * p.T + q] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward: workgroup = 64 keys of one head (4 waves x 16 keys); loops over the 64-query tiles at/below the diagonal
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnP p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE + 2 * 2 * 64 * 4];   // [stage][Q | dO], [stage][lse | D]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
+    const int kvt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, hk = h / (p.nh / p.nkv);
+    const int64_t ldq = (int64_t)p.nh * HD, ldk = (int64_t)p.nkv * HD;
+    const int kv0 = kvt * 64, kw0 = kv0 + 16 * w;
+    const int nqt = (int)(p.T / 64);
+    const bf16_t* qp = p.q + ((int64_t)b * p.T) * ldq + (int64_t)h * HD;
+    const bf16_t* gop = p.go + ((int64_t)b * p.T) * ldq + (int64_t)h * HD;
+    const bf16_t* kp = p.k + ((int64_t)b * p.T) * ldk + (int64_t)hk * HD;
+    const bf16_t* vp = p.v + ((int64_t)b * p.T) * ldk + (int64_t)hk * HD;
+    const float* lsep = p.lse + ((int64_t)b * p.nh + h) * p.T;
+    const float* dsp = p.dsum + ((int64_t)b * p.nh + h) * p.T;
+    bf16_t* dstp = p.dst + (((int64_t)b * p.nh + h) * p.T) * p.T;       // [key][query]
+    float* stat = reinterpret_cast<float*>(smem + 4 * TILE);
+
+    // zero the part of dS^T the dQ GEMM reads inside the diagonal 256-block but no (key tile, query tile) pair writes
+    {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+        const bf4 z = {(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        for (int qt = kvt & ~3; qt < kvt; ++qt)
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep) {
+                const int row = (tid >> 4) + 16 * rep, col = (tid & 15) * 4;
+                *reinterpret_cast<bf4*>(dstp + (int64_t)(kv0 + row) * p.T + qt * 64 + col) = z;
+            }
+    }
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *reinterpret_cast<const bf16x8*>(kp + (int64_t)(kw0 + c) * ldk + 32 * ks + 8 * g);
+        vf[ks] = *reinterpret_cast<const bf16x8*>(vp + (int64_t)(kw0 + c) * ldk + 32 * ks + 8 * g);
+    }
+    f32x4 dk[8], dv[8];
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+        dk[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    u32x4 rq[4], rg[4];
+    float rs = 0.f;
+    {
+        const int64_t q0 = (int64_t)kvt * 64;
+        tile_gload(qp + q0 * ldq, ldq, tid, rq);
+        tile_gload(gop + q0 * ldq, ldq, tid, rg);
+        if (tid < 128) rs = tid < 64 ? lsep[q0 + tid] : dsp[q0 + tid - 64];
+        tile_sstore(smem, tid, rq);
+        tile_sstore(smem + TILE, tid, rg);
+        if (tid < 128) stat[tid] = rs;
+    }
+    __syncthreads();
+    for (int qt = kvt; qt < nqt; ++qt) {
+        const int cur = (qt - kvt) & 1;
+        if (qt + 1 < nqt) {
+            const int64_t q1 = (int64_t)(qt + 1) * 64;
+            tile_gload(qp + q1 * ldq, ldq, tid, rq);
+            tile_gload(gop + q1 * ldq, ldq, tid, rg);
+            if (tid < 128) rs = tid < 64 ? lsep[q1 + tid] : dsp[q1 + tid - 64];
+        }
+        const char* Qs = smem + cur * 2 * TILE;
+        const char* Gs = Qs + TILE;
+        const float* lse_s = stat + cur * 128;
+        const float* d_s = lse_s + 64;
+        const int q0 = qt * 64;
+        const bool diag = qt == kvt;
+        f32x4 pb[4], sb[4];     // P and dS blocks: row = query 16qb+4g+i, col = key c
+#pragma unroll
+        for (int qb = 0; qb < 4; ++qb) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                s = MFMA(frag_row(Qs, 16 * qb, ks, lane), kf[ks], s);
+                dp = MFMA(frag_row(Gs, 16 * qb, ks, lane), vf[ks], dp);
+            }
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qb + 4 * g);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(d_s + 16 * qb + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float pv = __builtin_amdgcn_exp2f(s[i] * p.scale_log2 - l4[i]);
+                if (diag && kw0 + c > q0 + 16 * qb + 4 * g + i) pv = 0.f;
+                pb[qb][i] = pv;
+                sb[qb][i] = pv * (dp[i] - d4[i]) * p.scale;
+            }
+            // dS^T[key kw0+c][query q0+16qb+4g .. +4]
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+            bf4 dsv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dsv[i] = (bf16_t)sb[qb][i];
+            *reinterpret_cast<bf4*>(dstp + (int64_t)(kw0 + c) * p.T + q0 + 16 * qb + 4 * g) = dsv;
+        }
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const bf16x8 pf = pack8(pb[2 * kc], pb[2 * kc + 1]);      // B operand: k-slot = query, col = key c
+            const bf16x8 sf = pack8(sb[2 * kc], sb[2 * kc + 1]);
+#pragma unroll
+            for (int db = 0; db < 8; ++db) {
+                dv[db] = MFMA(frag_tr(Gs, 32 * kc, 16 * db, lane), pf, dv[db]);   // dV^T: row = d 16db+4g+i, col = key c
+                dk[db] = MFMA(frag_tr(Qs, 32 * kc, 16 * db, lane), sf, dk[db]);
+            }
+        }
+        if (qt + 1 < nqt) {
+            tile_sstore(smem + (cur ^ 1) * 2 * TILE, tid, rq);
+            tile_sstore(smem + (cur ^ 1) * 2 * TILE + TILE, tid, rg);
+            if (tid < 128) stat[(cur ^ 1) * 128 + tid] = rs;
+        }
+        __syncthreads();
+    }
+    bf16_t* gkp = p.gk + ((int64_t)b * p.T) * ldq + (int64_t)h * HD;
+    bf16_t* gvp = p.gv + ((int64_t)b * p.T) * ldq + (int64_t)h * HD;
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+        bf4 a, bb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = (bf16_t)dk[db][i]; bb[i] = (bf16_t)dv[db][i]; }
+        *reinterpret_cast<bf4*>(gkp + (int64_t)(kw0 + c) * ldq + 16 * db + 4 * g) = a;
+        *reinterpret_cast<bf4*>(gvp + (int64_t)(kw0 + c) * ldq + 16 * db + 4 * g) = bb;
+    }
+}
+
+int check_common(const char* who, int dtype, int64_t bs, int64_t T, int nh, int nkv, int hd, int causal) {
+    OQ_CHECK_ARG(dtype == OQ_BF16, "%s: bf16 only (the fp32 parity mode uses the unfused exact kernels)", who);
+    OQ_CHECK_ARG(hd == HD, "%s: head_dim %d unsupported (128 only)", who, hd);
+    OQ_CHECK_ARG(causal == 1, "%s: only the exact causal mask is fused", who);
+    OQ_CHECK_ARG(bs > 0 && bs <= 65535 && (T == 128 || (T > 0 && T % 256 == 0)),
+                 "%s: T=%lld must be 128 or a multiple of 256 (the causal dQ GEMM contracts in 256-blocks)", who, (long long)T);
+    OQ_CHECK_ARG(nh > 0 && nkv > 0 && nh % nkv == 0 && nh <= 65535, "%s: heads %d / kv heads %d", who, nh, nkv);
+    return OQ_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t oq_attn_supported(int dtype, int64_t T, int hd, int causal) {
+    return dtype == OQ_BF16 && hd == HD && causal == 1 && (T == 128 || (T > 0 && T % 256 == 0));
+}
+
+extern "C" int oq_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int dtype, int64_t bs,
+                           int64_t T, int nh, int nkv, int hd, float scale, int causal, void* stream) {
+    OQ_CHECK_ARG(q && k && v && o && lse, "oq_attn_fwd: null pointer");
+    if (int rc = check_common("oq_attn_fwd", dtype, bs, T, nh, nkv, hd, causal)) return rc;
+    OQ_CHECK_ARG(oq_aligned16(q) && oq_aligned16(k) && oq_aligned16(v) && oq_aligned16(o), "oq_attn_fwd: 16-B alignment");
+    AttnP p{};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
+    p.T = T; p.nh = nh; p.nkv = nkv; p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(T / 128), (unsigned)nh, (unsigned)bs), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    OQ_CHECK_LAUNCH("oq_attn_fwd");
+    return OQ_OK;
+}
+
+extern "C" int oq_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* go, const float* lse,
+                           float* dsum, void* ds_t, void* gk, void* gv, int dtype, int64_t bs, int64_t T, int nh, int nkv,
+                           int hd, float scale, int causal, void* stream) {
+    OQ_CHECK_ARG(q && k && v && o && go && lse && dsum && ds_t && gk && gv, "oq_attn_bwd: null pointer");
+    if (int rc = check_common("oq_attn_bwd", dtype, bs, T, nh, nkv, hd, causal)) return rc;
+    OQ_CHECK_ARG(oq_aligned16(q) && oq_aligned16(k) && oq_aligned16(v) && oq_aligned16(o) && oq_aligned16(go) &&
+                     oq_aligned16(ds_t) && oq_aligned16(gk) && oq_aligned16(gv) && oq_aligned16(lse) && oq_aligned16(dsum),
+                 "oq_attn_bwd: 16-B alignment");
+    AttnP p{};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)const_cast<void*>(o);
+    p.go = (const bf16_t*)go; p.lse = const_cast<float*>(lse); p.dsum = dsum; p.dst = (bf16_t*)ds_t;
+    p.gk = (bf16_t*)gk; p.gv = (bf16_t*)gv;
+    p.T = T; p.nh = nh; p.nkv = nkv; p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+    const int64_t nrows = bs * T * nh;
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, p,
+                       nrows);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(T / 64), (unsigned)nh, (unsigned)bs), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    OQ_CHECK_LAUNCH("oq_attn_bwd");
+    return OQ_OK;
+}

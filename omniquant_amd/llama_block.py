@@ -100,11 +100,19 @@ class QuantLlamaAttention(nn.Module):
                                  f"{attention_mask.size()}")
             mask = attention_mask[0, 0]
         causal = ops.mask_is_causal(attention_mask)   # exact causal mask -> the masked half is skipped everywhere
-        scores = self.qkt_matmul.scores(q, k, causal)               # [bs, nh, T, T], unscaled
-        probs = ops.SoftmaxFn.apply(scores, mask, 1.0 / math.sqrt(hd), causal)   # scale, +mask, clamp, f32 softmax
-        probs = self.pv_matmul.quant_x1(probs)
-        v = self.pv_matmul.quant_x2(v)
-        attn = self.pv_matmul.apply_probs(probs, v, causal)        # [bs, T, nh, hd]
+        pq = self.pv_matmul.x1_quantizer
+        p_identity = (not self.pv_matmul.use_act_quant) or pq.n_bits >= 16 or not pq.enable
+        if p_identity and ops.fused_attention_supported(q, causal):
+            # exact causal mask + identity p-quantiser (the reference default, 16 bit): one fused kernel per direction,
+            # the [nh, T, T] scores / probabilities never touch HBM
+            v = self.pv_matmul.quant_x2(v)
+            attn = ops.FusedCausalAttnFn.apply(q, k, v, 1.0 / math.sqrt(hd))
+        else:
+            scores = self.qkt_matmul.scores(q, k, causal)               # [bs, nh, T, T], unscaled
+            probs = ops.SoftmaxFn.apply(scores, mask, 1.0 / math.sqrt(hd), causal)   # scale, +mask, clamp, f32 softmax
+            probs = self.pv_matmul.quant_x1(probs)
+            v = self.pv_matmul.quant_x2(v)
+            attn = self.pv_matmul.apply_probs(probs, v, causal)        # [bs, T, nh, hd]
         attn = self.o_proj(attn.view(bsz, q_len, self.hidden_size))
         return attn, None, None
 

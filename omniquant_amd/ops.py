@@ -392,6 +392,59 @@ class SoftmaxFn(torch.autograd.Function):
         return gs, None, None, None
 
 
+def fused_attention_supported(q, causal):
+    """The fused causal-attention kernels cover bf16, head_dim 128, T == 128 or T % 256 == 0 and the exact causal mask; anything
+    else runs the unfused HIP kernels (oq_gemm + oq_softmax_*).  OQ_NO_FLASH=1 is an A/B switch."""
+    if os.environ.get("OQ_NO_FLASH") or not causal or q.dim() != 4:
+        return False
+    return bool(C.size_call("oq_attn_supported", C.dt(q), q.shape[1], q.shape[3], 1))
+
+
+class FusedCausalAttnFn(torch.autograd.Function):
+    """o = softmax(scale * q k^T + causal mask) v without materialising scores / probabilities
+    (models/int_llama_layer.py:143-163 with the p-quantiser at its 16-bit identity).  q [bs,T,nh,hd];
+    k, v [bs,T,nkv,hd] -> o [bs,T,nh,hd].  Backward: oq_attn_bwd (dK, dV, dS^T) + one causal oq_gemm for dQ."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        bs, T, nh, hd = q.shape
+        nkv = k.shape[2]
+        o = torch.empty_like(q)
+        lse = torch.empty((bs, nh, T), dtype=torch.float32, device=q.device)
+        C.call("oq_attn_fwd", C.ptr(q), C.ptr(k), C.ptr(v), C.ptr(o), C.fptr(lse), C.dt(q), bs, T, nh, nkv, hd,
+               float(scale), 1, C.stream())
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = float(scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, o, lse = ctx.saved_tensors
+        go = go.contiguous()
+        bs, T, nh, hd = q.shape
+        nkv = k.shape[2]
+        rep = nh // nkv
+        dsum = torch.empty_like(lse)
+        ds_t = torch.empty((bs, nh, T, T), dtype=q.dtype, device=q.device)
+        gk_full = torch.empty_like(q)
+        gv_full = torch.empty_like(q)
+        C.call("oq_attn_bwd", C.ptr(q), C.ptr(k), C.ptr(v), C.ptr(o), C.ptr(go), C.fptr(lse), C.fptr(dsum), C.ptr(ds_t),
+               C.ptr(gk_full), C.ptr(gv_full), C.dt(q), bs, T, nh, nkv, hd, ctx.scale, 1, C.stream())
+        gq = torch.empty_like(q)
+        for b in range(bs):
+            # dQ[t,d] = sum_t' dS^T[t',t] K[t',d]   (contraction limited to t' < m0 + tile)
+            gemm(ds_t, k, gq, T, hd, T, T, nkv * hd, nh * hd, False, False, batch_o=nkv, batch_i=rep,
+                 sa=(rep * T * T, T * T), sb=(hd, 0), sc=(rep * hd, hd),
+                 a_off=b * nh * T * T, b_off=b * T * nkv * hd, c_off=b * T * nh * hd, tri=2)
+        if rep == 1:
+            gk, gv = gk_full, gv_full
+        else:
+            gk = gk_full.view(bs, T, nkv, rep, hd).sum(dim=3)
+            gv = gv_full.view(bs, T, nkv, rep, hd).sum(dim=3)
+        return gq, gk, gv, None
+
+
 class AddFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):

@@ -383,3 +383,47 @@ def test_causal_attention_fast_path(dtype, Tn):
     for name, a, b in zip(("o", "gq", "gk", "gv"), outs[0], outs[1]):
         sc = float(a.float().abs().max())
         assert_close(b.detach().float() / sc, (a.detach().float() / sc).cpu().numpy(), tol, tol, f"causal {name}")
+
+
+@pytest.mark.parametrize("Tn,nh,nkv", [(128, 2, 2), (256, 4, 2), (768, 3, 3), (1024, 2, 1)])
+def test_fused_causal_attention(Tn, nh, nkv):
+    """oq_attn_fwd / oq_attn_bwd (+ the causal dQ GEMM) vs an fp64 restatement of
+    models/int_llama_layer.py:143-163 on the same bf16 inputs, and vs the unfused HIP kernels.
+    Tolerance: bf16 probabilities / gradients -> 2e-2 of the tensor's max (same bar as the unfused bf16 path)."""
+    from omniquant_amd import ops
+    bs, hd = 1, 128
+    g = torch.Generator().manual_seed(Tn + nh)
+    q = (torch.randn(bs, Tn, nh, hd, generator=g) * 1.5).to(torch.bfloat16)
+    k = torch.randn(bs, Tn, nkv, hd, generator=g).to(torch.bfloat16)
+    v = torch.randn(bs, Tn, nkv, hd, generator=g).to(torch.bfloat16)
+    Go = torch.randn(bs, Tn, nh, hd, generator=g).to(torch.bfloat16)
+    scale = 1.0 / math.sqrt(hd)
+    # fp64 reference
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    rep = nh // nkv
+    kk = kr.repeat_interleave(rep, dim=2)
+    vv = vr.repeat_interleave(rep, dim=2)
+    s = torch.einsum("bthd,bshd->bhts", qr, kk) * scale
+    s = s + torch.triu(torch.full((Tn, Tn), float("-inf"), dtype=torch.float64), 1)
+    o_ref = torch.einsum("bhts,bshd->bthd", torch.softmax(s, -1), vv)
+    (o_ref * Go.double()).sum().backward()
+    ref = (o_ref.detach(), qr.grad, kr.grad, vr.grad)
+    # fused HIP path
+    qd, kd, vd = (t.clone().to(DEV).requires_grad_(True) for t in (q, k, v))
+    assert ops.fused_attention_supported(qd, True)
+    o = ops.FusedCausalAttnFn.apply(qd, kd, vd, scale)
+    (o.float() * Go.to(DEV).float()).sum().backward()
+    got = (o, qd.grad, kd.grad, vd.grad)
+    # unfused HIP path
+    mask = torch.triu(torch.full((Tn, Tn), torch.finfo(torch.float32).min), 1).to(DEV)
+    qu, ku, vu = (t.clone().to(DEV).requires_grad_(True) for t in (q, k, v))
+    pu = ops.SoftmaxFn.apply(ops.AttnScoresFn.apply(qu, ku, True), mask, scale, True)
+    ou = ops.AttnPVFn.apply(pu, vu, True)
+    (ou.float() * Go.to(DEV).float()).sum().backward()
+    unf = (ou, qu.grad, ku.grad, vu.grad)
+    for name, a, r, u in zip(("o", "gq", "gk", "gv"), got, ref, unf):
+        sc = float(r.abs().max())
+        err = float((a.detach().double().cpu() - r).abs().max()) / sc
+        err_u = float((u.detach().double().cpu() - r).abs().max()) / sc
+        assert err < 2e-2, f"fused {name}: {err} (unfused path: {err_u})"
+        assert err < 2.0 * err_u + 4e-3, f"fused {name} is less accurate than the unfused kernels: {err} vs {err_u}"
