@@ -97,11 +97,92 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // ---------------------------------------------------------------------------------------------------
 // forward: workgroup = 128 queries of one head (4 waves x 32 queries), key/value tiles of 64 through LDS
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p) {
+// One key/value tile for one wave.  DIAG: the tile crosses the diagonal of this wave's queries (mask needed).
+// dq = (query index of lane's column) - (first key of the tile) - 4*(lane>>4): key 16kb+i is masked iff 16kb+i > dq.
+template <bool DIAG>
+__device__ __forceinline__ void fwd_tile(const char* Ks, const char* Vs, const bf16x8 (&qf)[2][4], f32x4 (&o)[2][8],
+                                         float (&m)[2], float (&l)[2], const int (&dq)[2], float c2, int lane) {
+    f32x4 st[4][2];
+    bf16x8 kf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kf[0][ks] = frag_row(Ks, 0, ks, lane);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        if (kb < 3) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[(kb + 1) & 1][ks] = frag_row(Ks, 16 * (kb + 1), ks, lane);
+        }
+        st[kb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        st[kb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            st[kb][0] = MFMA(kf[kb & 1][ks], qf[0][ks], st[kb][0]);     // S^T block: row = key 16kb+4g+i, col = query
+            st[kb][1] = MFMA(kf[kb & 1][ks], qf[1][ks], st[kb][1]);
+        }
+    }
+    bf16x8 vf[2];
+    vf[0] = frag_tr(Vs, 0, 0, lane);             // in flight under the softmax arithmetic
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (DIAG && 16 * kb + i > dq[qb]) st[kb][qb][i] = -INFINITY;
+                mx = vmax(mx, st[kb][qb][i]);
+            }
+        mx = vmax(mx, xor16(mx));
+        mx = vmax(mx, xor32(mx));
+        mx = vmax(m[qb], mx * c2);               // running maximum in the scaled log2 domain
+        const float alpha = __builtin_amdgcn_exp2f(m[qb] - mx);
+        m[qb] = mx;
+        float ls = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][qb][i], c2, -mx));
+                st[kb][qb][i] = pv;
+                ls += pv;
+            }
+        l[qb] = fmaf(l[qb], alpha, ls);
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {       // wave-uniform: most late tiles leave the maxima alone
+#pragma unroll
+            for (int db = 0; db < 8; ++db)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[qb][db][i] *= alpha;
+        }
+    }
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+        const bf16x8 p0 = pack8(st[2 * kc][0], st[2 * kc + 1][0]);
+        const bf16x8 p1 = pack8(st[2 * kc][1], st[2 * kc + 1][1]);
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+            const int nx = kc * 8 + db + 1;
+            if (nx < 16) vf[nx & 1] = frag_tr(Vs, 32 * (nx >> 3), 16 * (nx & 7), lane);   // V^T: row = d 16db+(lane&15)
+            o[0][db] = MFMA(vf[(nx - 1) & 1], p0, o[0][db]);        // O^T block: row = d 16db+4g+i, col = query
+            o[1][db] = MFMA(vf[(nx - 1) & 1], p1, o[1][db]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p, int nqt, int nhb) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [stage][K | V]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int qt = (int)gridDim.x - 1 - (int)blockIdx.x;          // heaviest (longest key range) tiles first
-    const int h = blockIdx.y, b = blockIdx.z, hk = h / (p.nh / p.nkv);
+    // Work placement (speed only): items sorted heaviest-first (rank r: qt = nqt-1 - r/nhb) are dealt round-robin to
+    // the 8 XCDs (id % 8), and inside an XCD the second half of the local sequence is reversed, so the two
+    // workgroups that share a CU (local n and n + per/2 under round-robin dispatch) are a heavy and a light one.
+    const int total = nqt * nhb;
+    int r = blockIdx.x;
+    if (total % 16 == 0) {
+        const int per = total / 8, xcd = r & 7, n = r >> 3;
+        const int j = n < per / 2 ? n : per - 1 - (n - per / 2);
+        r = j * 8 + xcd;
+    }
+    const int qt = nqt - 1 - r / nhb, hb = r % nhb;
+    const int h = hb % p.nh, b = hb / p.nh, hk = h / (p.nh / p.nkv);
     const int64_t ldq = (int64_t)p.nh * HD, ldk = (int64_t)p.nkv * HD;
     const int q0 = qt * 128, qw0 = q0 + 32 * w;
     const bf16_t* qp = p.q + ((int64_t)b * p.T) * ldq + (int64_t)h * HD;
@@ -130,6 +211,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p) {
     tile_gload(vp, ldk, tid, rv);
     tile_sstore(smem, tid, rk);
     tile_sstore(smem + TILE, tid, rv);
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing (q fragments included) is pending at loop entry
     __syncthreads();
     for (int j = 0; j < ntiles; ++j) {
         const int cur = j & 1;
@@ -141,62 +223,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p) {
         const char* Vs = Ks + TILE;
         const int kpos0 = 64 * j;
         if (kpos0 <= qw0 + 31) {     // wave-uniform: this wave has at least one unmasked (query, key) pair in the tile
-            f32x4 st[4][2];
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                st[kb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-                st[kb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kf = frag_row(Ks, 16 * kb, ks, lane);
-                    st[kb][0] = MFMA(kf, qf[0][ks], st[kb][0]);     // S^T block: row = key 16kb+4g+i, col = query c
-                    st[kb][1] = MFMA(kf, qf[1][ks], st[kb][1]);
-                }
-            }
-            const bool diag = kpos0 + 63 > qw0;
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
-                const int qi = qw0 + 16 * qb + c;
-                float mx = m[qb];
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float s = st[kb][qb][i] * p.scale_log2;
-                        if (diag && kpos0 + 16 * kb + 4 * g + i > qi) s = -INFINITY;
-                        st[kb][qb][i] = s;
-                        mx = vmax(mx, s);
-                    }
-                mx = vmax(mx, xor16(mx));
-                mx = vmax(mx, xor32(mx));
-                const float alpha = __builtin_amdgcn_exp2f(m[qb] - mx);
-                m[qb] = mx;
-                float ls = 0.f;
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float pv = __builtin_amdgcn_exp2f(st[kb][qb][i] - mx);
-                        st[kb][qb][i] = pv;
-                        ls += pv;
-                    }
-                l[qb] = l[qb] * alpha + ls;
-#pragma unroll
-                for (int db = 0; db < 8; ++db)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) o[qb][db][i] *= alpha;
-            }
-#pragma unroll
-            for (int kc = 0; kc < 2; ++kc) {
-                const bf16x8 p0 = pack8(st[2 * kc][0], st[2 * kc + 1][0]);
-                const bf16x8 p1 = pack8(st[2 * kc][1], st[2 * kc + 1][1]);
-#pragma unroll
-                for (int db = 0; db < 8; ++db) {
-                    const bf16x8 vf = frag_tr(Vs, 32 * kc, 16 * db, lane);   // V^T: row = d 16db+(lane&15)
-                    o[0][db] = MFMA(vf, p0, o[0][db]);                        // O^T block: row = d 16db+4g+i, col = query
-                    o[1][db] = MFMA(vf, p1, o[1][db]);
-                }
-            }
+            const int dq[2] = {qw0 + c - kpos0 - 4 * g, qw0 + 16 + c - kpos0 - 4 * g};
+            if (kpos0 + 63 > qw0) fwd_tile<true>(Ks, Vs, qf, o, m, l, dq, p.scale_log2, lane);
+            else fwd_tile<false>(Ks, Vs, qf, o, m, l, dq, p.scale_log2, lane);
         }
         if (j + 1 < ntiles) {
             tile_sstore(smem + (cur ^ 1) * 2 * TILE, tid, rk);
@@ -249,10 +278,76 @@ __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(AttnP p, int64_t nro
 // ---------------------------------------------------------------------------------------------------
 // backward: workgroup = 64 keys of one head (4 waves x 16 keys); loops over the 64-query tiles at/below the diagonal
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnP p) {
+// One 64-query tile for one wave (16 keys).  DIAG: the diagonal tile; query 16qb+4g+i is masked iff 16qb+i < mk
+// (mk = key - first query of the tile - 4g, per lane).
+template <bool DIAG>
+__device__ __forceinline__ void bwd_phase1(const char* Qs, const char* Gs, const float* lse_s, const float* d_s,
+                                           const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], bf16x8 (&pf)[2], bf16x8 (&sf)[2],
+                                           bf16_t* dst_row, int mk, float c2, float scale, int lane) {
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
+    const int g = lane >> 4;
+    f32x4 pprev = {0.f, 0.f, 0.f, 0.f}, sprev = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 qa[4], ga[4];
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qa[ks] = frag_row(Qs, 16 * qb, ks, lane);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ga[ks] = frag_row(Gs, 16 * qb, ks, lane);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qb + 4 * g);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(d_s + 16 * qb + 4 * g);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = MFMA(qa[ks], kf[ks], s);        // row = query 16qb+4g+i, col = key
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dp = MFMA(ga[ks], vf[ks], dp);
+        f32x4 pv, sv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float e = __builtin_amdgcn_exp2f(fmaf(s[i], c2, -l4[i]));
+            if (DIAG && 16 * qb + i < mk) e = 0.f;
+            pv[i] = e;
+            sv[i] = e * (dp[i] - d4[i]) * scale;
+        }
+        bf4 dsv;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dsv[i] = (bf16_t)sv[i];
+        *reinterpret_cast<bf4*>(dst_row + 16 * qb) = dsv;           // dS^T[key][query 16qb+4g .. +4]
+        if (qb & 1) {
+            pf[qb >> 1] = pack8(pprev, pv);                        // B operand: k-slot = query, col = key
+            sf[qb >> 1] = pack8(sprev, sv);
+        } else {
+            pprev = pv;
+            sprev = sv;
+        }
+    }
+}
+
+// dV^T += dO^T P, dK^T += Q^T dS for one 64-query tile (the contraction runs over the queries)
+__device__ __forceinline__ void bwd_phase2(const char* Qs, const char* Gs, const bf16x8 (&pf)[2], const bf16x8 (&sf)[2],
+                                           f32x4 (&dk)[8], f32x4 (&dv)[8], int lane) {
+    bf16x8 tg[2], tq[2];
+    tg[0] = frag_tr(Gs, 0, 0, lane);
+    tq[0] = frag_tr(Qs, 0, 0, lane);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int kc = it >> 3, db = it & 7, nx = it + 1;
+        if (nx < 16) {
+            tg[nx & 1] = frag_tr(Gs, 32 * (nx >> 3), 16 * (nx & 7), lane);
+            tq[nx & 1] = frag_tr(Qs, 32 * (nx >> 3), 16 * (nx & 7), lane);
+        }
+        dv[db] = MFMA(tg[it & 1], pf[kc], dv[db]);     // dV^T: row = d 16db+4g+i, col = key
+        dk[db] = MFMA(tq[it & 1], sf[kc], dk[db]);
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnP p, int nhb) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE + 2 * 2 * 64 * 4];   // [stage][Q | dO], [stage][lse | D]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
-    const int kvt = blockIdx.x, h = blockIdx.y, b = blockIdx.z, hk = h / (p.nh / p.nkv);
+    // heaviest key tiles (kvt = 0: all query tiles) first; consecutive ids = different heads of the same key tile, so
+    // the round-robin id -> XCD placement gives every XCD the same mix
+    const int kvt = (int)blockIdx.x / nhb, hb = (int)blockIdx.x % nhb;
+    const int h = hb % p.nh, b = hb / p.nh, hk = h / (p.nh / p.nkv);
     const int64_t ldq = (int64_t)p.nh * HD, ldk = (int64_t)p.nkv * HD;
     const int kv0 = kvt * 64, kw0 = kv0 + 16 * w;
     const int nqt = (int)(p.T / 64);
@@ -288,9 +383,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnP p) {
         dk[db] = f32x4{0.f, 0.f, 0.f, 0.f};
         dv[db] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    u32x4 rq[4], rg[4];
+    u32x4 rq[4];
     float rs = 0.f;
     {
+        u32x4 rg[4];
         const int64_t q0 = (int64_t)kvt * 64;
         tile_gload(qp + q0 * ldq, ldq, tid, rq);
         tile_gload(gop + q0 * ldq, ldq, tid, rg);
@@ -299,61 +395,33 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnP p) {
         tile_sstore(smem + TILE, tid, rg);
         if (tid < 128) stat[tid] = rs;
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): k/v fragments and the zero-fill stores are done
     __syncthreads();
+    bf16_t* dst_row = dstp + (int64_t)(kw0 + c) * p.T + 4 * g;
     for (int qt = kvt; qt < nqt; ++qt) {
         const int cur = (qt - kvt) & 1;
-        if (qt + 1 < nqt) {
-            const int64_t q1 = (int64_t)(qt + 1) * 64;
+        const bool more = qt + 1 < nqt;
+        const int64_t q1 = (int64_t)(qt + 1) * 64;
+        if (more) {            // staging in two halves (Q under phase 1, dO under phase 2): 16 registers instead of 32
             tile_gload(qp + q1 * ldq, ldq, tid, rq);
-            tile_gload(gop + q1 * ldq, ldq, tid, rg);
             if (tid < 128) rs = tid < 64 ? lsep[q1 + tid] : dsp[q1 + tid - 64];
         }
         const char* Qs = smem + cur * 2 * TILE;
         const char* Gs = Qs + TILE;
         const float* lse_s = stat + cur * 128;
-        const float* d_s = lse_s + 64;
-        const int q0 = qt * 64;
-        const bool diag = qt == kvt;
-        f32x4 pb[4], sb[4];     // P and dS blocks: row = query 16qb+4g+i, col = key c
-#pragma unroll
-        for (int qb = 0; qb < 4; ++qb) {
-            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                s = MFMA(frag_row(Qs, 16 * qb, ks, lane), kf[ks], s);
-                dp = MFMA(frag_row(Gs, 16 * qb, ks, lane), vf[ks], dp);
-            }
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * qb + 4 * g);
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(d_s + 16 * qb + 4 * g);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float pv = __builtin_amdgcn_exp2f(s[i] * p.scale_log2 - l4[i]);
-                if (diag && kw0 + c > q0 + 16 * qb + 4 * g + i) pv = 0.f;
-                pb[qb][i] = pv;
-                sb[qb][i] = pv * (dp[i] - d4[i]) * p.scale;
-            }
-            // dS^T[key kw0+c][query q0+16qb+4g .. +4]
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
-            bf4 dsv;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dsv[i] = (bf16_t)sb[qb][i];
-            *reinterpret_cast<bf4*>(dstp + (int64_t)(kw0 + c) * p.T + q0 + 16 * qb + 4 * g) = dsv;
-        }
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            const bf16x8 pf = pack8(pb[2 * kc], pb[2 * kc + 1]);      // B operand: k-slot = query, col = key c
-            const bf16x8 sf = pack8(sb[2 * kc], sb[2 * kc + 1]);
-#pragma unroll
-            for (int db = 0; db < 8; ++db) {
-                dv[db] = MFMA(frag_tr(Gs, 32 * kc, 16 * db, lane), pf, dv[db]);   // dV^T: row = d 16db+4g+i, col = key c
-                dk[db] = MFMA(frag_tr(Qs, 32 * kc, 16 * db, lane), sf, dk[db]);
-            }
-        }
-        if (qt + 1 < nqt) {
+        bf16x8 pf[2], sf[2];
+        if (qt == kvt)
+            bwd_phase1<true>(Qs, Gs, lse_s, lse_s + 64, kf, vf, pf, sf, dst_row + qt * 64, 16 * w + c - 4 * g,
+                             p.scale_log2, p.scale, lane);
+        else
+            bwd_phase1<false>(Qs, Gs, lse_s, lse_s + 64, kf, vf, pf, sf, dst_row + qt * 64, 0, p.scale_log2, p.scale, lane);
+        if (more) {
             tile_sstore(smem + (cur ^ 1) * 2 * TILE, tid, rq);
-            tile_sstore(smem + (cur ^ 1) * 2 * TILE + TILE, tid, rg);
             if (tid < 128) stat[(cur ^ 1) * 128 + tid] = rs;
+            tile_gload(gop + q1 * ldq, ldq, tid, rq);
         }
+        bwd_phase2(Qs, Gs, pf, sf, dk, dv, lane);
+        if (more) tile_sstore(smem + (cur ^ 1) * 2 * TILE + TILE, tid, rq);
         __syncthreads();
     }
     bf16_t* gkp = p.gk + ((int64_t)b * p.T) * ldq + (int64_t)h * HD;
@@ -393,8 +461,10 @@ extern "C" int oq_attn_fwd(const void* q, const void* k, const void* v, void* o,
     AttnP p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (bf16_t*)o; p.lse = lse;
     p.T = T; p.nh = nh; p.nkv = nkv; p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(T / 128), (unsigned)nh, (unsigned)bs), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    const int nqt = (int)(T / 128);
+    OQ_CHECK_ARG((int64_t)nqt * nh * bs < (1ll << 30), "oq_attn_fwd: too many workgroups");
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(nqt * nh * bs)), dim3(256), 0, (hipStream_t)stream, p, nqt,
+                       (int)(nh * bs));
     OQ_CHECK_LAUNCH("oq_attn_fwd");
     return OQ_OK;
 }
@@ -415,8 +485,9 @@ extern "C" int oq_attn_bwd(const void* q, const void* k, const void* v, const vo
     const int64_t nrows = bs * T * nh;
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, p,
                        nrows);
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)(T / 64), (unsigned)nh, (unsigned)bs), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    OQ_CHECK_ARG((T / 64) * nh * bs < (1ll << 30), "oq_attn_bwd: too many workgroups");
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((T / 64) * nh * bs)), dim3(256), 0, (hipStream_t)stream, p,
+                       (int)(nh * bs));
     OQ_CHECK_LAUNCH("oq_attn_bwd");
     return OQ_OK;
 }
