@@ -42,7 +42,7 @@ const char* oq_last_error(void);
  *   symmetric:    s = clamp(max(|hi'|,|lo'|)/(2^(n-1)-1), 1e-5, 1e4),  z = 2^(n-1)-1
  *   y = (clamp(rne(x/s)+z, 0, 2^n-1) - z) * s
  *   wshift[r] = sum_c w[r,c]*shift[c]                                      (optional by-product)
- * Outputs: y [rows,cols] (y_dtype); scale, zp, xmin, xmax [rows*cols/seg] f32 (each may be NULL).
+ * Outputs: y [rows,cols] (y_dtype); scale, zp, xmin, xmax [rows*cols/seg] f32 (all required; xmin/xmax feed oq_fakequant_bwd).
  * Requirements: cols % seg == 0, seg % 8 == 0, and seg/8 a power of two when seg <= 512.
  */
 int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits, int symmetric,
@@ -60,7 +60,7 @@ int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int
  */
 int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits, int symmetric,
                      const float* col_mul, const float* row_div, const float* row_mul, const float* shift,
-                     const float* up, const float* low,
+                     const float* up, const float* low, const float* xmin, const float* xmax,
                      const void* g, int g_dtype, const float* g_wshift,
                      float* g_up, float* g_low, void* gx, int gx_dtype,
                      float* g_col_mul, float* g_shift, float* g_row_div, float* g_row_mul,

@@ -22,7 +22,7 @@ struct FQ {
     const float *col_mul, *row_div, *row_mul, *shift, *up, *low;
     // fwd
     void* y;
-    float *scale, *zp, *xmin, *xmax, *wshift;
+    float *scale, *zp, *xmin, *xmax, *wshift;      // bwd READS xmin / xmax (written by the forward)
     // bwd
     const void* g;
     const float* g_wshift;
@@ -123,7 +123,11 @@ __device__ __forceinline__ QP make_qp(float hi, float lo, bool lwc, float up_log
 // A workgroup walks rows r = blockIdx.x, +gridDim.x, ...; the NEXT row's 16-byte chunks are already in flight (raw
 // registers) while the current row is reduced and quantised, so HBM requests never drain between rows.  Everything
 // that depends only on the column (col_mul, shift, segment index) is loaded once per workgroup.
-template <typename TIN, typename TOUT, bool LET, int CH>
+// No divergent branch surrounds a global load or store inside the row loop (FULL: every lane owns a chunk; otherwise
+// the surplus lanes redo the row's LAST chunk -- same inputs, same outputs, benign duplicate stores -- and are masked
+// out of the sums): the compiler can then count outstanding memory operations and waits only for the prefetched row
+// (vmcnt(N)), not for the previous row's stores to be acknowledged (vmcnt(0), a full memory round trip per row).
+template <typename TIN, typename TOUT, bool LET, int CH, bool FULL>
 __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
     __shared__ float red[3 * 16];
     const int t = threadIdx.x, BT = blockDim.x;
@@ -135,38 +139,43 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
 
     bool valid[CH];
-    int c0[CH], segi[CH];
+    int cc[CH], segi[CH];
     constexpr int NL = LET ? CH : 1;
     float cmv[NL][8], shv[NL][8];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-        c0[j] = (j * BT + t) * 8;
-        valid[j] = c0[j] < p.cols;
-        segi[j] = (int)((uint32_t)c0[j] / (uint32_t)p.seg);
+        const int c0 = (j * BT + t) * 8;
+        valid[j] = FULL || c0 < p.cols;
+        // surplus lanes redo the last chunk (whole-row segments) or, group-wise, the last segment (short segments)
+        cc[j] = valid[j] ? c0 : (small ? (int)(p.cols - p.seg) + (t & (lps - 1)) * 8 : (int)p.cols - 8);
+        segi[j] = (int)((uint32_t)cc[j] / (uint32_t)p.seg);
         if constexpr (LET) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                cmv[j][i] = (valid[j] && p.col_mul) ? p.col_mul[c0[j] + i] : 1.f;
-                shv[j][i] = (valid[j] && p.shift) ? p.shift[c0[j] + i] : 0.f;
+                cmv[j][i] = p.col_mul ? p.col_mul[cc[j] + i] : 1.f;
+                shv[j][i] = (valid[j] && p.shift) ? p.shift[cc[j] + i] : 0.f;
             }
         }
     }
     Raw8<TIN> nxt[CH];
     float nup[CH], nlow[CH], nrd = 1.f, nrm = 1.f;   // next row's LWC logits / row factors, prefetched with its data
     const bool lwc = p.up != nullptr;
+    const float* upp = lwc ? p.up : p.scale;          // dummy (ignored) source when LWC is off: keeps the loads unconditional
+    const float* lowp = lwc ? p.low : p.scale;
 #pragma unroll
     for (int j = 0; j < CH; ++j) { nup[j] = 0.f; nlow[j] = 0.f; }
-    int64_t r = blockIdx.x;
-    if (r < p.rows) {
+    auto prefetch = [&](int64_t r) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j)
-            if (valid[j]) {
-                nxt[j].load(wbase + r * p.cols + c0[j]);
-                if (lwc) { nup[j] = p.up[r * nseg + segi[j]]; nlow[j] = p.low[r * nseg + segi[j]]; }
-            }
+        for (int j = 0; j < CH; ++j) {
+            nxt[j].load(wbase + r * p.cols + cc[j]);
+            nup[j] = upp[r * nseg + segi[j]];
+            nlow[j] = lowp[r * nseg + segi[j]];
+        }
         if (LET && p.row_div) nrd = p.row_div[r];
         if (LET && p.row_mul) nrm = p.row_mul[r];
-    }
+    };
+    int64_t r = blockIdx.x;
+    if (r < p.rows) prefetch(r);
     for (; r < p.rows; r += gridDim.x) {
         float x[CH][8], cup[CH], clow[CH];
         const float rd = nrd, rm = nrm;
@@ -174,25 +183,15 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
         for (int j = 0; j < CH; ++j) {
             cup[j] = nup[j];
             clow[j] = nlow[j];
-            if (valid[j]) nxt[j].unpack(x[j]);
+            nxt[j].unpack(x[j]);
         }
         const int64_t rn = r + gridDim.x;
-        if (rn < p.rows) {
-#pragma unroll
-            for (int j = 0; j < CH; ++j)
-                if (valid[j]) {
-                    nxt[j].load(wbase + rn * p.cols + c0[j]);
-                    if (lwc) { nup[j] = p.up[rn * nseg + segi[j]]; nlow[j] = p.low[rn * nseg + segi[j]]; }
-                }
-            if (LET && p.row_div) nrd = p.row_div[rn];
-            if (LET && p.row_mul) nrm = p.row_mul[rn];
-        }
+        if (rn < p.rows) prefetch(rn);
         float dot = 0.f;
         const float inv_rd = 1.f / rd;
         if constexpr (LET) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if (valid[j]) {
+            for (int j = 0; j < CH; ++j) {
                 if (p.shift) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) dot += x[j][i] * shv[j][i];
@@ -211,7 +210,6 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
                 }
             }
         }
-        }
         // ---- min / max (NaN-propagating like torch.amax/amin) ---------------------------------
         float hi[CH], lo[CH], bad[CH];
 #pragma unroll
@@ -219,13 +217,11 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
             hi[j] = -INFINITY;
             lo[j] = INFINITY;
             bad[j] = 0.f;
-            if (valid[j]) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    hi[j] = vmax(hi[j], x[j][i]);
-                    lo[j] = vmin(lo[j], x[j][i]);
-                    bad[j] = (x[j][i] != x[j][i]) ? 1.f : bad[j];
-                }
+            for (int i = 0; i < 8; ++i) {
+                hi[j] = vmax(hi[j], x[j][i]);
+                lo[j] = vmin(lo[j], x[j][i]);
+                bad[j] = (x[j][i] != x[j][i]) ? 1.f : bad[j];
             }
         }
         if (small) {
@@ -254,7 +250,6 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
         q.s = 1.f; q.z = 0.f; q.su = q.sl = 1.f; q.hi = q.lo = 0.f;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            if (!valid[j]) continue;
             const int64_t sidx = r * nseg + segi[j];
             float h = hi[j], l = lo[j];
             if (bad[j] != 0.f) { h = NAN; l = NAN; }
@@ -281,13 +276,13 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
                     yv[i] = (v - q.z) * q.s;
                 }
             }
-            Vec8<TOUT>::store(ybase + r * p.cols + c0[j], yv);
-            const bool leader = small ? ((t & (lps - 1)) == 0) : (t == 0 && j == 0);
-            if (leader) {
-                if (p.scale) p.scale[sidx] = q.s;
-                if (p.zp) p.zp[sidx] = q.z;
-                if (p.xmin) p.xmin[sidx] = l;
-                if (p.xmax) p.xmax[sidx] = h;
+            Vec8<TOUT>::store(ybase + r * p.cols + cc[j], yv);
+            // per-segment statistics: every lane of the segment stores the same value (no divergent branch)
+            if (small || j == 0) {
+                p.scale[sidx] = q.s;
+                p.zp[sidx] = q.z;
+                p.xmin[sidx] = l;
+                p.xmax[sidx] = h;
             }
         }
         if (LET && p.wshift) {
@@ -302,9 +297,15 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
-template <typename TIN, typename TG, bool LET, int CH>
+// ONE pass over the row and ONE block reduction per row: the segment min/max come from the forward (p.xmin/p.xmax),
+// the pass accumulates gs, the tie counts and the "inside the clip range" part of every LET gradient, and the two
+// straight-through terms that flow through max/min (they touch only the elements EQUAL to the row max/min) are patched
+// in afterwards by the few waves that hold such an element.  Row-factor gradients use the closed forms
+//   g_row_mul = sum_in G*b + (g_hi*su*hi + g_lo*sl*lo) / rm          (every tie element has b = x / rm)
+//   g_row_div = -(rm / rd) * g_row_mul
+template <typename TIN, typename TG, bool LET, int CH, bool FULL>
 __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
-    __shared__ float red[3 * 16];
+    __shared__ float red[4 * 16];
     const int t = threadIdx.x, BT = blockDim.x;
     const bool small = p.seg <= 512;
     const int lps = small ? (int)(p.seg >> 3) : 64;
@@ -313,9 +314,10 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
     const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
     const TG* gbase = reinterpret_cast<const TG*>(p.g);
     TG* gxbase = reinterpret_cast<TG*>(p.gx);
-    const bool need_let = LET && (p.g_col_mul || p.g_row_div || p.g_row_mul);
-    const bool need_gx = p.gx || need_let;
+    const bool need_cm = LET && p.g_col_mul;
+    const bool need_row = LET && (p.g_row_div || p.g_row_mul);
     const bool need_sh = LET && p.g_shift;
+    const bool need_tie = p.gx || need_cm;
 
     constexpr int NACC = LET ? CH : 1;
     float acc_cm[NACC][8], acc_sh[NACC][8], cmv[NACC][8];
@@ -324,145 +326,140 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) { acc_cm[j][i] = 0.f; acc_sh[j][i] = 0.f; cmv[j][i] = 1.f; }
     bool valid[CH];
-    int c0[CH], segi[CH];
+    int cc[CH], segi[CH];
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
-        c0[j] = (j * BT + t) * 8;
-        valid[j] = c0[j] < p.cols;
-        segi[j] = (int)((uint32_t)c0[j] / (uint32_t)p.seg);
+        const int c0 = (j * BT + t) * 8;
+        valid[j] = FULL || c0 < p.cols;
+        // surplus lanes redo the last chunk (whole-row segments) or, group-wise, the last segment (short segments);
+        // they store the same values again and are masked out of every sum (see fq_fwd_kernel)
+        cc[j] = valid[j] ? c0 : (small ? (int)(p.cols - p.seg) + (t & (lps - 1)) * 8 : (int)p.cols - 8);
+        segi[j] = (int)((uint32_t)cc[j] / (uint32_t)p.seg);
         if constexpr (LET) {
-            if (valid[j] && p.col_mul) {
+            if (p.col_mul) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) cmv[j][i] = p.col_mul[c0[j] + i];
+                for (int i = 0; i < 8; ++i) cmv[j][i] = p.col_mul[cc[j] + i];
             }
         }
     }
     Raw8<TIN> nw[CH];
     Raw8<TG> ng[CH];
-    float nup[CH], nlow[CH], nrd = 1.f, nrm = 1.f, ngws = 0.f;
+    float nup[CH], nlow[CH], nhi_[CH], nlo_[CH], nrd = 1.f, nrm = 1.f, ngws = 0.f;
     const bool lwc = p.up != nullptr;
+    // per-segment statistics of the NEXT row ride along with its data; loaded unconditionally into their own
+    // registers (dummy pointers when LWC is off) so that no select has to wait for them
+    const float* upp = lwc ? p.up : p.xmax;
+    const float* lowp = lwc ? p.low : p.xmin;
 #pragma unroll
-    for (int j = 0; j < CH; ++j) { nup[j] = 0.f; nlow[j] = 0.f; }
-    int64_t r = blockIdx.x;
-    if (r < p.rows) {
+    for (int j = 0; j < CH; ++j) { nup[j] = 0.f; nlow[j] = 0.f; nhi_[j] = 0.f; nlo_[j] = 0.f; }
+    auto prefetch = [&](int64_t r) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j)
-            if (valid[j]) {
-                nw[j].load(wbase + r * p.cols + c0[j]);
-                ng[j].load(gbase + r * p.cols + c0[j]);
-                if (lwc) { nup[j] = p.up[r * nseg + segi[j]]; nlow[j] = p.low[r * nseg + segi[j]]; }
-            }
+        for (int j = 0; j < CH; ++j) {
+            nw[j].load(wbase + r * p.cols + cc[j]);
+            ng[j].load(gbase + r * p.cols + cc[j]);
+            const int64_t sidx = r * nseg + segi[j];
+            nhi_[j] = p.xmax[sidx];
+            nlo_[j] = p.xmin[sidx];
+            nup[j] = upp[sidx];
+            nlow[j] = lowp[sidx];
+        }
         if (LET && p.row_div) nrd = p.row_div[r];
         if (LET && p.row_mul) nrm = p.row_mul[r];
         if (LET && p.g_wshift) ngws = p.g_wshift[r];
-    }
+    };
+    int64_t r = blockIdx.x;
+    if (r < p.rows) prefetch(r);
     for (; r < p.rows; r += gridDim.x) {
-        float w[CH][8], x[CH][8], G[CH][8], cup[CH], clow[CH];
+        float w[CH][8], x[CH][8], G[CH][8], cup[CH], clow[CH], hi[CH], lo[CH];
         const float rd = nrd, rm = nrm, gws = ngws;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             cup[j] = nup[j];
             clow[j] = nlow[j];
-            if (valid[j]) { nw[j].unpack(w[j]); ng[j].unpack(G[j]); }
+            hi[j] = nhi_[j];
+            lo[j] = nlo_[j];
+            nw[j].unpack(w[j]);
+            ng[j].unpack(G[j]);
         }
         const int64_t rn = r + gridDim.x;
-        if (rn < p.rows) {
-#pragma unroll
-            for (int j = 0; j < CH; ++j)
-                if (valid[j]) {
-                    nw[j].load(wbase + rn * p.cols + c0[j]);
-                    ng[j].load(gbase + rn * p.cols + c0[j]);
-                    if (lwc) { nup[j] = p.up[rn * nseg + segi[j]]; nlow[j] = p.low[rn * nseg + segi[j]]; }
-                }
-            if (LET && p.row_div) nrd = p.row_div[rn];
-            if (LET && p.row_mul) nrm = p.row_mul[rn];
-            if (LET && p.g_wshift) ngws = p.g_wshift[rn];
-        }
+        if (rn < p.rows) prefetch(rn);
         const float inv_rd = 1.f / rd;      // gradient path only: reciprocal multiplies instead of IEEE divides
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            if (valid[j]) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float v = w[j][i];
-                    if constexpr (LET) {
-                        if (p.col_mul) v = v * cmv[j][i];
-                        if (p.row_div) v = div_nr(v, rd, inv_rd);   // same function as the forward: x is bit-identical
-                        if (p.row_mul) v = v * rm;                  // (ties with hi/lo and the clip mask depend on it)
-                    }
-                    x[j][i] = v;
-                }
-            }
-        }
-        float hi[CH], lo[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            hi[j] = -INFINITY;
-            lo[j] = INFINITY;
-            if (valid[j]) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { hi[j] = vmax(hi[j], x[j][i]); lo[j] = vmin(lo[j], x[j][i]); }
-            }
-        }
-        if (small) {
-#pragma unroll
-            for (int j = 0; j < CH; ++j) { hi[j] = wave_max(hi[j], lps); lo[j] = wave_min(lo[j], lps); }
-        } else {
-            float v[2] = {-INFINITY, INFINITY};
-#pragma unroll
-            for (int j = 0; j < CH; ++j) { v[0] = fmaxf(v[0], hi[j]); v[1] = fminf(v[1], lo[j]); }
-            const int op[2] = {1, 2};
-            block_reduce<2>(v, op, red);
-#pragma unroll
-            for (int j = 0; j < CH; ++j) { hi[j] = v[0]; lo[j] = v[1]; }
-        }
-        // ---- gs = sum G * d y/d s ; tie counts -------------------------------------------------
+        const float rmrd = rm * inv_rd;
         QP qp[CH];
-        float gs[CH], nhi[CH], nlo[CH], inv_s[CH];
+        float gs[CH], inv_s[CH], acc_rm = 0.f;
+        int chi[CH], clo[CH];
+        float gin[CH][8];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            gs[j] = 0.f; nhi[j] = 0.f; nlo[j] = 0.f; inv_s[j] = 0.f;
-            if (valid[j]) {
-                if (small || j == 0) {
-                    qp[j] = make_qp(hi[j], lo[j], lwc, cup[j], clow[j], p.nbits, p.symmetric);
-                    inv_s[j] = 1.f / qp[j].s;
-                } else {
-                    qp[j] = qp[0];        // whole-row segment: every chunk shares the row's parameters
-                    inv_s[j] = inv_s[0];
-                }
+            gs[j] = 0.f; chi[j] = 0; clo[j] = 0;
+            if (small || j == 0) {
+                qp[j] = make_qp(hi[j], lo[j], lwc, cup[j], clow[j], p.nbits, p.symmetric);
+                inv_s[j] = 1.f / qp[j].s;
+            } else {
+                qp[j] = qp[0];
+                inv_s[j] = inv_s[0];
+            }
+            const float z = qp[j].z;
+            const float live = (FULL || valid[j]) ? 1.f : 0.f;   // surplus lanes contribute nothing to the sums
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float tq = x[j][i] * inv_s[j];
-                    const float v = rne_ste(tq) + qp[j].z;
-                    const bool in = (v >= 0.f) && (v <= Q);
-                    const float qv = vmin(vmax(v, 0.f), Q);
-                    gs[j] += G[j][i] * ((qv - qp[j].z) - (in ? tq : 0.f));
-                    nhi[j] += (x[j][i] == hi[j]) ? 1.f : 0.f;
-                    nlo[j] += (x[j][i] == lo[j]) ? 1.f : 0.f;
+            for (int i = 0; i < 8; ++i) {
+                float v = w[j][i];
+                if constexpr (LET) {
+                    if (p.col_mul) v = v * cmv[j][i];
+                    if (p.row_div) v = div_nr(v, rd, inv_rd);   // same function as the forward: x is bit-identical
+                    if (p.row_mul) v = v * rm;                  // (ties with hi/lo and the clip mask depend on it)
+                }
+                x[j][i] = v;
+                const float tq = v * inv_s[j];
+                const float u = rne_ste(tq) + z;
+                const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
+                const bool in = qv == u;                        // inside [0, Q] (false for NaN)
+                // block-wide sums (whole-row segments, row factors) skip the surplus lanes; group-wide sums of the
+                // short-segment mode do not: a surplus GROUP recomputes the last segment completely
+                const float Gr = FULL ? G[j][i] : G[j][i] * live;
+                const float Gg = (FULL || small) ? G[j][i] : Gr;
+                const bool cnt = FULL || small || valid[j];
+                gs[j] = fmaf(Gg, (qv - z) - (in ? tq : 0.f), gs[j]);
+                chi[j] += (v == hi[j] && cnt) ? 1 : 0;
+                clo[j] += (v == lo[j] && cnt) ? 1 : 0;
+                gin[j][i] = in ? G[j][i] : 0.f;
+                if constexpr (LET) {
+                    const float gi = in ? Gr : 0.f;
+                    if (need_row) {
+                        const float b = (w[j][i] * cmv[j][i]) * inv_rd;     // x = b * rm
+                        acc_rm = fmaf(gi, b, acc_rm);
+                    }
+                    if (need_cm) acc_cm[j][i] = fmaf(gi * rmrd, w[j][i], acc_cm[j][i]);
+                    if (need_sh) acc_sh[j][i] = fmaf(gws, w[j][i], acc_sh[j][i]);
                 }
             }
         }
+        int mine = 0;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) mine |= chi[j] | clo[j];
+        float nhi[CH], nlo[CH];
         if (small) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 gs[j] = wave_sum(gs[j], lps);
-                nhi[j] = wave_sum(nhi[j], lps);
-                nlo[j] = wave_sum(nlo[j], lps);
+                nhi[j] = wave_sum((float)chi[j], lps);
+                nlo[j] = wave_sum((float)clo[j], lps);
             }
         } else {
-            float v[3] = {0.f, 0.f, 0.f};
+            float v[4] = {0.f, 0.f, 0.f, acc_rm};
 #pragma unroll
-            for (int j = 0; j < CH; ++j) { v[0] += gs[j]; v[1] += nhi[j]; v[2] += nlo[j]; }
-            const int op[3] = {0, 0, 0};
-            block_reduce<3>(v, op, red);
+            for (int j = 0; j < CH; ++j) { v[0] += gs[j]; v[1] += (float)chi[j]; v[2] += (float)clo[j]; }
+            const int op[4] = {0, 0, 0, 0};
+            block_reduce<4>(v, op, red);
 #pragma unroll
             for (int j = 0; j < CH; ++j) { gs[j] = v[0]; nhi[j] = v[1]; nlo[j] = v[2]; }
+            acc_rm = v[3];
         }
-        // ---- d s / d hi', d s / d lo'  (hi' = su*hi, lo' = sl*lo) --------------------------------
-        float acc_rd = 0.f, acc_rm = 0.f;
+        // ---- d s / d hi', d s / d lo'  (hi' = su*hi, lo' = sl*lo), LWC gradients, tie terms ------
+        const bool any_tie = need_tie && __builtin_amdgcn_ballot_w64(mine != 0) != 0;   // wave-uniform
+        float row_tie = 0.f;        // grouped segments: sum over this thread's segments of the tie part of g_row_mul
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            if (!valid[j]) continue;
             const int64_t sidx = r * nseg + segi[j];
             const QP q = qp[j];
             float ds_dhs, ds_dls;   // d scale / d hi', d scale / d lo'
@@ -483,47 +480,48 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
             }
             const float g_hs = gs[j] * ds_dhs;   // dL/d hi'
             const float g_ls = gs[j] * ds_dls;   // dL/d lo'
-            const bool leader = small ? ((t & (lps - 1)) == 0) : (t == 0 && j == 0);
-            if (leader) {
+            // every lane of the segment stores the same LWC gradients (no divergent branch around the store)
+            if (small || j == 0) {
                 if (p.g_up) p.g_up[sidx] = g_hs * q.hi * q.su * (1.f - q.su);
                 if (p.g_low) p.g_low[sidx] = g_ls * q.lo * q.sl * (1.f - q.sl);
             }
-            if (need_gx || need_sh) {
-                float gxv[8];
+            if constexpr (LET) {
+                if (need_row) {
+                    const float tie = g_hs * q.su * q.hi + g_ls * q.sl * q.lo;
+                    if (small) {
+                        if ((t & (lps - 1)) == 0 && (FULL || valid[j])) row_tie += tie;   // one lane per segment
+                    } else if (j == 0) {
+                        const float tot = acc_rm + tie / rm;
+                        if (p.g_row_mul) p.g_row_mul[r] = tot;          // same value from every lane
+                        if (p.g_row_div) p.g_row_div[r] = -rmrd * tot;
+                    }
+                }
+            }
+            if (any_tie) {
                 const float tie_hi = g_hs * q.su / nhi[j], tie_lo = g_ls * q.sl / nlo[j];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float tq = x[j][i] * inv_s[j];
-                    const float v = rne_ste(tq) + q.z;
-                    const bool in = (v >= 0.f) && (v <= Q);
-                    float gv = in ? G[j][i] : 0.f;
-                    if (x[j][i] == q.hi) gv += tie_hi;
-                    if (x[j][i] == q.lo) gv += tie_lo;
-                    gxv[i] = gv;
-                    if constexpr (LET) {
-                        if (need_let) {
-                            // x = ((w*cm)/rd)*rm ; b = (w*cm)/rd
-                            const float a = w[j][i] * cmv[j][i];
-                            const float b = a * inv_rd;
-                            acc_rm += gv * b;
-                            const float gb = gv * rm;
-                            acc_rd += gb * (-b * inv_rd);
-                            acc_cm[j][i] += (gb * inv_rd) * w[j][i];
+                    float tt = 0.f;
+                    if (x[j][i] == q.hi) tt += tie_hi;
+                    if (x[j][i] == q.lo) tt += tie_lo;
+                    if (x[j][i] == q.hi || x[j][i] == q.lo) {
+                        gin[j][i] += tt;
+                        if constexpr (LET) {
+                            if (need_cm) acc_cm[j][i] = fmaf(tt * rmrd, w[j][i], acc_cm[j][i]);
                         }
-                        if (need_sh) acc_sh[j][i] += gws * w[j][i];
                     }
                 }
-                if (p.gx) Vec8<TG>::store(gxbase + r * p.cols + c0[j], gxv);
             }
+            if (p.gx) Vec8<TG>::store(gxbase + r * p.cols + cc[j], gin[j]);
         }
         if constexpr (LET) {
-            if (p.g_row_div || p.g_row_mul) {
-                float v[2] = {acc_rd, acc_rm};
-                const int op[2] = {0, 0};
-                block_reduce<2>(v, op, red);
+            if (need_row && small) {
+                float v[1] = {acc_rm + row_tie / rm};
+                const int op[1] = {0};
+                block_reduce<1>(v, op, red);
                 if (t == 0) {
-                    if (p.g_row_div) p.g_row_div[r] = v[0];
-                    if (p.g_row_mul) p.g_row_mul[r] = v[1];
+                    if (p.g_row_mul) p.g_row_mul[r] = v[0];
+                    if (p.g_row_div) p.g_row_div[r] = -rmrd * v[0];
                 }
             }
         }
@@ -536,8 +534,8 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (valid[j]) {
-                if (p.g_col_mul) Vec8<float>::store(wcm + c0[j], acc_cm[j]);
-                if (p.g_shift) Vec8<float>::store(wsh + c0[j], acc_sh[j]);
+                if (p.g_col_mul) Vec8<float>::store(wcm + cc[j], acc_cm[j]);
+                if (p.g_shift) Vec8<float>::store(wsh + cc[j], acc_sh[j]);
             }
         }
       }
@@ -616,7 +614,11 @@ int check_shape(const char* fn, int64_t rows, int64_t cols, int64_t seg, int nbi
 
 }  // namespace
 
-#define FQ_LAUNCH_FWD(TIN, TOUT, L, C_) hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, L, C_>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p)
+#define FQ_LAUNCH_FWD(TIN, TOUT, L, C_)                                                                              \
+    do {                                                                                                             \
+        if (full) hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, L, C_, true>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);  \
+        else hipLaunchKernelGGL((fq_fwd_kernel<TIN, TOUT, L, C_, false>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);      \
+    } while (0)
 #define FQ_DISPATCH_FWD(TIN, TOUT)                                     \
     do {                                                               \
         if (let) {                                                     \
@@ -639,6 +641,7 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     int rc = check_shape("oq_fakequant_fwd", rows, cols, seg, nbits);
     if (rc) return rc;
     OQ_CHECK_ARG(w && y, "oq_fakequant_fwd: null w/y");
+    OQ_CHECK_ARG(scale && zp && xmin && xmax, "oq_fakequant_fwd: scale/zp/xmin/xmax outputs are required");
     OQ_CHECK_ARG(oq_aligned16(w) && oq_aligned16(y), "oq_fakequant_fwd: w/y must be 16-byte aligned");
     OQ_CHECK_ARG((up == nullptr) == (low == nullptr), "oq_fakequant_fwd: up/low must both be given or both NULL");
     OQ_CHECK_ARG(!wshift || shift, "oq_fakequant_fwd: wshift requested without shift");
@@ -649,6 +652,7 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     const bool let = col_mul || row_div || row_mul || shift;
     int ch, bt;
     row_geometry(cols, 2, &ch, &bt);
+    const bool full = (int64_t)ch * bt * 8 == cols;
     const int64_t gcap = dbg_env("OQ_DBG_FQ_BLOCKS", OQ_FQ_MAX_BLOCKS);
     const int64_t grid = rows < gcap ? rows : gcap;
     const int key = w_dtype * 3 + y_dtype;
@@ -666,7 +670,11 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     return OQ_OK;
 }
 
-#define FQ_LAUNCH_BWD(TIN, TG, L, C_) hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, L, C_>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p)
+#define FQ_LAUNCH_BWD(TIN, TG, L, C_)                                                                              \
+    do {                                                                                                           \
+        if (full) hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, L, C_, true>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);  \
+        else hipLaunchKernelGGL((fq_bwd_kernel<TIN, TG, L, C_, false>), dim3(grid), dim3(bt), 0, (hipStream_t)stream, p);      \
+    } while (0)
 #define FQ_DISPATCH_BWD(TIN, TG)                                     \
     do {                                                             \
         if (let) {                                                   \
@@ -684,13 +692,15 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
 
 extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits,
                                 int symmetric, const float* col_mul, const float* row_div, const float* row_mul,
-                                const float* shift, const float* up, const float* low, const void* g, int g_dtype,
+                                const float* shift, const float* up, const float* low, const float* xmin,
+                                const float* xmax, const void* g, int g_dtype,
                                 const float* g_wshift, float* g_up, float* g_low, void* gx, int gx_dtype,
                                 float* g_col_mul, float* g_shift, float* g_row_div, float* g_row_mul,
                                 float* workspace, int64_t workspace_floats, void* stream) {
     int rc = check_shape("oq_fakequant_bwd", rows, cols, seg, nbits);
     if (rc) return rc;
     OQ_CHECK_ARG(w && g, "oq_fakequant_bwd: null w/g");
+    OQ_CHECK_ARG(xmin && xmax, "oq_fakequant_bwd: xmin/xmax (the forward's per-segment min/max) are required");
     OQ_CHECK_ARG(oq_aligned16(w) && oq_aligned16(g) && oq_aligned16(gx), "oq_fakequant_bwd: 16-byte alignment");
     OQ_CHECK_ARG(!gx || gx_dtype == g_dtype, "oq_fakequant_bwd: gx dtype must equal g dtype");
     OQ_CHECK_ARG((up == nullptr) == (low == nullptr), "oq_fakequant_bwd: up/low must both be given or both NULL");
@@ -702,11 +712,13 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
     p.w = w; p.rows = rows; p.cols = cols; p.seg = seg; p.nbits = nbits; p.symmetric = symmetric;
     p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = shift; p.up = up; p.low = low;
     p.g = g; p.g_wshift = g_wshift; p.g_up = g_up; p.g_low = g_low; p.gx = gx;
+    p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax);
     p.g_col_mul = g_col_mul; p.g_shift = g_shift; p.g_row_div = g_row_div; p.g_row_mul = g_row_mul;
     // the LET instantiation is needed whenever the transform is present (x must be recomputed), not only for its grads
     const bool let = col_mul || row_div || row_mul || g_col_mul || g_shift || g_row_div || g_row_mul;
     int ch, bt;
     row_geometry(cols, 2, &ch, &bt);
+    const bool full = (int64_t)ch * bt * 8 == cols;
     // column accumulators are flushed once per workgroup: keep the grid small when they are live
     const int64_t cap = (g_col_mul || g_shift) ? OQ_FQ_BWD_MAX_BLOCKS : dbg_env("OQ_DBG_FQ_BLOCKS", OQ_FQ_MAX_BLOCKS);
     const int64_t grid = rows < cap ? rows : cap;

@@ -43,14 +43,17 @@ class FakeQuantFn(torch.autograd.Function):
         y = torch.empty(w.shape, dtype=out_dtype, device=w.device)
         scale = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
         zp = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
+        xmin = torch.empty((nseg,), dtype=torch.float32, device=w.device)     # consumed by the backward kernel
+        xmax = torch.empty((nseg,), dtype=torch.float32, device=w.device)
         wshift = torch.empty((rows,), dtype=torch.float32, device=w.device) if shift is not None else None
         cm, rd, rm, sh, u, l = (_f32(t) for t in (col_mul, row_div, row_mul, shift, up, low))
         C.call("oq_fakequant_fwd", C.ptr(w), C.dt(w), rows, cols, seg, nbits, int(symmetric),
                C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l),
-               C.ptr(y), C._DT[out_dtype], C.fptr(scale), C.fptr(zp), None, None, C.fptr(wshift), C.stream())
+               C.ptr(y), C._DT[out_dtype], C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.fptr(wshift),
+               C.stream())
         if stash is not None:
             stash["scale"], stash["zp"] = scale, zp
-        ctx.save_for_backward(w, cm, rd, rm, sh, u, l)
+        ctx.save_for_backward(w, cm, rd, rm, sh, u, l, xmin, xmax)
         ctx.cfg = (rows, cols, seg, nbits, int(symmetric))
         if wshift is None:
             wshift = torch.empty((0,), device=w.device)   # placeholder output, never used (no kernel launched)
@@ -62,7 +65,7 @@ class FakeQuantFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, gwshift):
-        w, cm, rd, rm, sh, u, l = ctx.saved_tensors
+        w, cm, rd, rm, sh, u, l, xmin, xmax = ctx.saved_tensors
         rows, cols, seg, nbits, symmetric = ctx.cfg
         need = ctx.needs_input_grad   # w, col_mul, row_div, row_mul, shift, up, low
         dev = w.device
@@ -86,7 +89,7 @@ class FakeQuantFn(torch.autograd.Function):
             ws_n = C.size_call("oq_fakequant_bwd_workspace", rows, cols)
             ws = torch.empty((ws_n,), dtype=torch.float32, device=dev)
         C.call("oq_fakequant_bwd", C.ptr(w), C.dt(w), rows, cols, seg, nbits, symmetric,
-               C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l),
+               C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l), C.fptr(xmin), C.fptr(xmax),
                C.ptr(gy), C.dt(gy), C.fptr(gws), C.fptr(g_up), C.fptr(g_low), C.ptr(gx), C.dt(gy),
                C.fptr(g_cm), C.fptr(g_sh), C.fptr(g_rd), C.fptr(g_rm), C.fptr(ws), ws_n, C.stream())
         if gx is not None and gx.dtype != w.dtype:

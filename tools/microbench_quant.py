@@ -22,13 +22,15 @@ g_rd = torch.empty(rows, device=dev)
 ws_n = C.size_call("oq_fakequant_bwd_workspace", rows, cols); ws = torch.empty(ws_n, device=dev)
 y = torch.empty(rows, cols, device=dev, dtype=torch.bfloat16)
 sc, zp, wsh = torch.empty(rows, device=dev), torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+xmn, xmx = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
 P = C.fptr; st = C.stream()
 def bwd(cm_, rd_, sh_, gws_, gcm_, gsh_, grd_, x=W, g=G, gx=None):
-    C.call("oq_fakequant_bwd", C.ptr(x), C.dt(x), rows, cols, cols, 4, 0, P(cm_), P(rd_), None, P(sh_), P(up), P(low),
+    C.call("oq_fakequant_bwd", C.ptr(x), C.dt(x), rows, cols, cols, 4, 0, P(cm_), P(rd_), None, P(sh_), P(up), P(low), P(xmn), P(xmx),
            C.ptr(g), C.dt(g), P(gws_), P(g_up), P(g_low), C.ptr(gx), C.dt(g), P(gcm_), P(gsh_), P(grd_), None, P(ws), ws_n, st)
 def fwd(cm_, rd_, sh_, wsh_):
     C.call("oq_fakequant_fwd", C.ptr(W), C.dt(W), rows, cols, cols, 4, 0, P(cm_), P(rd_), None, P(sh_), P(up), P(low),
-           C.ptr(y), 2, P(sc), P(zp), None, None, P(wsh_), st)
+           C.ptr(y), 2, P(sc), P(zp), P(xmn), P(xmx), P(wsh_), st)
+fwd(cm, rd, sh, wsh)
 print("bwd LET full        ", timeit(lambda: bwd(cm, rd, sh, gws, g_cm, g_sh, g_rd)))
 print("bwd LET no colgrads ", timeit(lambda: bwd(cm, rd, None, None, None, None, g_rd)))
 print("bwd LET colmul only ", timeit(lambda: bwd(cm, None, None, None, g_cm, None, None)))
@@ -36,6 +38,7 @@ print("bwd LWC only        ", timeit(lambda: bwd(None, None, None, None, None, N
 print("fwd LET full        ", timeit(lambda: fwd(cm, rd, sh, wsh)))
 print("fwd LWC only        ", timeit(lambda: fwd(None, None, None, None)))
 X = torch.randn(2048, 4096, device=dev).bfloat16(); GX = torch.empty_like(X)
+xmn = X.float().amin(1).contiguous(); xmx = X.float().amax(1).contiguous()
 rows = 2048
 up = low = None
 g_up = g_low = None
