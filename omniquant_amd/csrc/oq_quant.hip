@@ -19,6 +19,7 @@ struct FQ {
     const void* w;
     int64_t rows, cols, seg;
     int nbits, symmetric;
+    float inv_q;          // 1 / (2^nbits - 1), correctly rounded on the host
     const float *col_mul, *row_div, *row_mul, *shift, *up, *low;
     // fwd
     void* y;
@@ -34,10 +35,12 @@ struct FQ {
 
 // block-wide reduction of up to 3 values; op: 0 sum, 1 max, 2 min.  All threads must call.
 template <int NV>
-__device__ __forceinline__ void block_reduce(float (&v)[NV], const int (&op)[NV], float* red /*[NV*16]*/) {
+__device__ __forceinline__ void block_reduce(float (&v)[NV], const int (&op)[NV], float* red /*[NV*16]*/,
+                                             unsigned wave_uniform = 0 /* bit i: v[i] is already a per-wave value */) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
+        if ((wave_uniform >> i) & 1) continue;
         v[i] = op[i] == 0 ? wave_sum(v[i]) : (op[i] == 1 ? wave_max(v[i]) : wave_min(v[i]));
     }
     if (nw == 1) return;
@@ -92,8 +95,13 @@ __device__ __forceinline__ float rne_ste(float t) {
     return (r - t) + t;
 }
 
+// Scale / zero-point of one segment.  The asymmetric branch avoids the ~12-instruction IEEE division expansion (every
+// thread of the row runs this once per row): (hs-ls)/Q is formed by the Markstein sequence q0 = a*(1/Q),
+// q1 = fma(fma(-q0, Q, a), 1/Q, q0), which is the correctly rounded quotient for the integer divisors 2^n-1 used here
+// (1/Q correctly rounded, exact fma residual); the zero-point uses the reciprocal-multiply + exact fallback of rne_div.
+// `inv_s` is only ever used inside rne_div-style verified rounding, so v_rcp_f32 (1 ulp) is accurate enough.
 __device__ __forceinline__ QP make_qp(float hi, float lo, bool lwc, float up_logit, float low_logit, int nbits,
-                                      int symmetric) {
+                                      int symmetric, float invQ, float* inv_s_out) {
     QP q;
     q.hi = hi;
     q.lo = lo;
@@ -107,12 +115,25 @@ __device__ __forceinline__ QP make_qp(float hi, float lo, bool lwc, float up_log
         if (hs != hs || ls != ls) s = hs + ls;               // keep NaN
         q.s = (s != s) ? s : fminf(fmaxf(s, 1e-5f), 1e4f);
         q.z = lv;
+        *inv_s_out = __builtin_amdgcn_rcpf(q.s);
     } else {
         const float Q = (float)((1 << nbits) - 1);
-        q.s = (hs - ls) / Q;                                 // not clamped: reference quirk Q1
-        float zp = -ls / q.s;
-        zp = (zp != zp) ? zp : fminf(fmaxf(zp, -1e4f), 1e4f);
-        q.z = rintf(zp);
+        const float a = hs - ls;
+        const float q0 = a * invQ;
+        float sc = fmaf(fmaf(-q0, Q, a), invQ, q0);          // == a / Q (not clamped: reference quirk Q1)
+        if (!(fabsf(a) >= 1e-30f && fabsf(a) <= 1e30f)) sc = a / Q;   // zero / tiny / huge / NaN: plain division
+        q.s = sc;
+        const float inv_s = __builtin_amdgcn_rcpf(sc);
+        *inv_s_out = inv_s;
+        float zp = -ls * inv_s;
+        const float rz = rintf(zp);
+        if (!(fabsf(zp - rz) <= fmaf(-4e-7f, fabsf(zp), 0.5f)) || !(fabsf(zp) < 9.9e3f)) {
+            zp = -ls / sc;                                   // near a rounding boundary, at the clamp, inf or NaN
+            zp = (zp != zp) ? zp : fminf(fmaxf(zp, -1e4f), 1e4f);
+            q.z = rintf(zp);
+        } else {
+            q.z = rz;
+        }
     }
     return q;
 }
@@ -211,18 +232,20 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
             }
         }
         // ---- min / max (NaN-propagating like torch.amax/amin) ---------------------------------
+        // NaN test: one v_cmp_u per element into a wave mask that is OR-ed on the scalar unit
         float hi[CH], lo[CH], bad[CH];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             hi[j] = -INFINITY;
             lo[j] = INFINITY;
-            bad[j] = 0.f;
+            uint64_t nanm = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 hi[j] = vmax(hi[j], x[j][i]);
                 lo[j] = vmin(lo[j], x[j][i]);
-                bad[j] = (x[j][i] != x[j][i]) ? 1.f : bad[j];
+                nanm |= __builtin_amdgcn_fcmpf(x[j][i], x[j][i], 8);       // FCMP_UNO
             }
+            bad[j] = ((nanm >> (threadIdx.x & 63)) & 1) ? 1.f : 0.f;
         }
         if (small) {
 #pragma unroll
@@ -255,18 +278,30 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
             if (bad[j] != 0.f) { h = NAN; l = NAN; }
             // whole-row segments: scale / zero-point / 1/scale are the same for every chunk of the thread -> once
             if (small || j == 0) {
-                q = make_qp(h, l, lwc, cup[j], clow[j], p.nbits, p.symmetric);
-                inv_s = 1.f / q.s;
+                q = make_qp(h, l, lwc, cup[j], clow[j], p.nbits, p.symmetric, p.inv_q, &inv_s);
             }
             float yv[8];
             if (q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad[j] == 0.f) {
                 // regular segment (finite non-zero scale, no NaN): no special values can appear below
+                // rne(x / s) as rne(x * (1/s)); the (rare) lanes whose product lies within ~2 ulp of a half-integer redo
+                // the exact division -- tested for the whole chunk with ONE wave-uniform branch
+                float rq[8];
+                uint64_t susp = 0;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    float tq;
-                    const float v = vmin(vmax(rne_div(x[j][i], q.s, inv_s, &tq) + q.z, 0.f), Q);
-                    yv[i] = (v - q.z) * q.s;
+                    const float tq = x[j][i] * inv_s;
+                    rq[i] = rintf(tq);
+                    susp |= __builtin_amdgcn_fcmpf(fabsf(tq - rq[i]), fmaf(-4e-7f, fabsf(tq), 0.5f), 2);   // FCMP_OGT
                 }
+                if (susp != 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float tq = x[j][i] * inv_s;
+                        if (fabsf(tq - rq[i]) > fmaf(-4e-7f, fabsf(tq), 0.5f)) rq[i] = rintf(x[j][i] / q.s);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) yv[i] = (__builtin_amdgcn_fmed3f(rq[i] + q.z, 0.f, Q) - q.z) * q.s;
             } else {
                 // degenerate segment (constant row -> scale 0, inf/NaN inputs): replay the reference's op sequence
 #pragma unroll
@@ -387,20 +422,23 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
         const float rmrd = rm * inv_rd;
         QP qp[CH];
         float gs[CH], inv_s[CH], acc_rm = 0.f;
-        int chi[CH], clo[CH];
+        int chi[CH], clo[CH], whi = 0, wlo = 0;     // tie counts: per lane (short segments) / per wave (whole rows)
         float gin[CH][8];
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             gs[j] = 0.f; chi[j] = 0; clo[j] = 0;
             if (small || j == 0) {
-                qp[j] = make_qp(hi[j], lo[j], lwc, cup[j], clow[j], p.nbits, p.symmetric);
-                inv_s[j] = 1.f / qp[j].s;
+                qp[j] = make_qp(hi[j], lo[j], lwc, cup[j], clow[j], p.nbits, p.symmetric, p.inv_q, &inv_s[j]);
             } else {
                 qp[j] = qp[0];
                 inv_s[j] = inv_s[0];
             }
             const float z = qp[j].z;
             const float live = (FULL || valid[j]) ? 1.f : 0.f;   // surplus lanes contribute nothing to the sums
+            // regular segment (finite non-zero scale): round(t) needs no inf -> NaN replay of the reference's
+            // (round(t) - t) + t, which equals rint(t) for every finite t
+            const bool regular = qp[j].s != 0.f && fabsf(qp[j].s) <= 3.4028234663852886e38f;
+            const uint64_t vmask = FULL ? ~0ull : __builtin_amdgcn_ballot_w64(valid[j]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float v = w[j][i];
@@ -411,17 +449,22 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
                 }
                 x[j][i] = v;
                 const float tq = v * inv_s[j];
-                const float u = rne_ste(tq) + z;
+                const float u = (regular ? rintf(tq) : rne_ste(tq)) + z;
                 const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
                 const bool in = qv == u;                        // inside [0, Q] (false for NaN)
                 // block-wide sums (whole-row segments, row factors) skip the surplus lanes; group-wide sums of the
                 // short-segment mode do not: a surplus GROUP recomputes the last segment completely
                 const float Gr = FULL ? G[j][i] : G[j][i] * live;
                 const float Gg = (FULL || small) ? G[j][i] : Gr;
-                const bool cnt = FULL || small || valid[j];
                 gs[j] = fmaf(Gg, (qv - z) - (in ? tq : 0.f), gs[j]);
-                chi[j] += (v == hi[j] && cnt) ? 1 : 0;
-                clo[j] += (v == lo[j] && cnt) ? 1 : 0;
+                if (small) {
+                    chi[j] += (v == hi[j]) ? 1 : 0;
+                    clo[j] += (v == lo[j]) ? 1 : 0;
+                } else {
+                    // whole-row segments: one v_cmp per element, counted per wave on the scalar unit
+                    whi += __builtin_popcountll(__builtin_amdgcn_fcmpf(v, hi[j], 1) & vmask);      // FCMP_OEQ
+                    wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(v, lo[j], 1) & vmask);
+                }
                 gin[j][i] = in ? G[j][i] : 0.f;
                 if constexpr (LET) {
                     const float gi = in ? Gr : 0.f;
@@ -434,29 +477,31 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
                 }
             }
         }
-        int mine = 0;
-#pragma unroll
-        for (int j = 0; j < CH; ++j) mine |= chi[j] | clo[j];
         float nhi[CH], nlo[CH];
+        bool wave_tie;
         if (small) {
+            int mine = 0;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
+                mine |= chi[j] | clo[j];
                 gs[j] = wave_sum(gs[j], lps);
                 nhi[j] = wave_sum((float)chi[j], lps);
                 nlo[j] = wave_sum((float)clo[j], lps);
             }
+            wave_tie = __builtin_amdgcn_ballot_w64(mine != 0) != 0;
         } else {
-            float v[4] = {0.f, 0.f, 0.f, acc_rm};
+            wave_tie = (whi | wlo) != 0;
+            float v[4] = {0.f, (float)whi, (float)wlo, acc_rm};
 #pragma unroll
-            for (int j = 0; j < CH; ++j) { v[0] += gs[j]; v[1] += (float)chi[j]; v[2] += (float)clo[j]; }
+            for (int j = 0; j < CH; ++j) v[0] += gs[j];
             const int op[4] = {0, 0, 0, 0};
-            block_reduce<4>(v, op, red);
+            block_reduce<4>(v, op, red, 0x6u);
 #pragma unroll
             for (int j = 0; j < CH; ++j) { gs[j] = v[0]; nhi[j] = v[1]; nlo[j] = v[2]; }
             acc_rm = v[3];
         }
         // ---- d s / d hi', d s / d lo'  (hi' = su*hi, lo' = sl*lo), LWC gradients, tie terms ------
-        const bool any_tie = need_tie && __builtin_amdgcn_ballot_w64(mine != 0) != 0;   // wave-uniform
+        const bool any_tie = need_tie && wave_tie;                                      // wave-uniform
         float row_tie = 0.f;        // grouped segments: sum over this thread's segments of the tie part of g_row_mul
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
@@ -647,6 +692,7 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     OQ_CHECK_ARG(!wshift || shift, "oq_fakequant_fwd: wshift requested without shift");
     FQ p{};
     p.w = w; p.rows = rows; p.cols = cols; p.seg = seg; p.nbits = nbits; p.symmetric = symmetric;
+    p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = wshift ? shift : nullptr;
     p.up = up; p.low = low; p.y = y; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax; p.wshift = wshift;
     const bool let = col_mul || row_div || row_mul || shift;
@@ -710,6 +756,7 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
     OQ_CHECK_ARG(!g_row_mul || row_mul, "oq_fakequant_bwd: g_row_mul needs row_mul");
     FQ p{};
     p.w = w; p.rows = rows; p.cols = cols; p.seg = seg; p.nbits = nbits; p.symmetric = symmetric;
+    p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = shift; p.up = up; p.low = low;
     p.g = g; p.g_wshift = g_wshift; p.g_up = g_up; p.g_low = g_low; p.gx = gx;
     p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax);
