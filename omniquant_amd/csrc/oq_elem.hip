@@ -26,19 +26,22 @@ __global__ void rope_kernel(const T* x, T* y, int64_t Tn, int64_t heads, int64_t
         const int64_t tt = th / heads;
         const T* px = x + th * hd;
         T* py = y + th * hd;
-        float a[8], b[8], oa[8], ob[8];
+        float a[8], b[8], oa[8], ob[8], c1[8], s1[8], c2[8], s2[8];
         Vec8<T>::load(px + d0, a);
         Vec8<T>::load(px + half + d0, b);
+        // tables are [T, hd] f32 and L2-resident: four 32-byte vector reads instead of 32 scalar ones
+        Vec8<float>::load(cs + tt * hd + d0, c1);
+        Vec8<float>::load(sn + tt * hd + d0, s1);
+        Vec8<float>::load(cs + tt * hd + half + d0, c2);
+        Vec8<float>::load(sn + tt * hd + half + d0, s2);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float c1 = cs[tt * hd + d0 + i], s1 = sn[tt * hd + d0 + i];
-            const float c2 = cs[tt * hd + half + d0 + i], s2 = sn[tt * hd + half + d0 + i];
             if (!inverse) {
-                oa[i] = a[i] * c1 + (-b[i]) * s1;
-                ob[i] = b[i] * c2 + a[i] * s2;
+                oa[i] = a[i] * c1[i] + (-b[i]) * s1[i];
+                ob[i] = b[i] * c2[i] + a[i] * s2[i];
             } else {
-                oa[i] = a[i] * c1 + b[i] * s2;
-                ob[i] = b[i] * c2 - a[i] * s1;
+                oa[i] = a[i] * c1[i] + b[i] * s2[i];
+                ob[i] = b[i] * c2[i] - a[i] * s1[i];
             }
         }
         Vec8<T>::store(py + d0, oa);

@@ -63,11 +63,18 @@ __global__ void __launch_bounds__(1024) norm_fwd_kernel(const T* x, int64_t rows
         for (int j = 0; j < MAXCH; ++j) {
             if (!valid[j]) continue;
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
-            float o[8];
+            float o[8], wv[8], bv[8];
+            Vec8<float>::load(w + c0, wv);               // 32-byte vector reads (were 16 scalar loads per chunk)
+            if (b) {
+                Vec8<float>::load(b + c0, bv);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bv[i] = 0.f;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float xh = (v[j][i] - mean) * rstd;
-                o[i] = w[c0 + i] * xh + (b ? b[c0 + i] : 0.f);
+                o[i] = wv[i] * xh + bv[i];
             }
             Vec8<T>::store(y + r * cols + c0, o);
         }
@@ -85,6 +92,17 @@ __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, 
     for (int j = 0; j < MAXCH; ++j)
 #pragma unroll
         for (int i = 0; i < 8; ++i) { aw[j][i] = 0.f; ab[j][i] = 0.f; }
+    float wv[MAXCH][8];                       // the norm weight of this thread's columns: loaded once, as vectors
+#pragma unroll
+    for (int j = 0; j < MAXCH; ++j) {
+        const int64_t c0 = ((int64_t)j * BT + t) * 8;
+        if (c0 < cols) {
+            Vec8<float>::load(w + c0, wv[j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wv[j][i] = 0.f;
+        }
+    }
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float rstd = rstd_in[r];
         const float mean = (ln && mean_in) ? mean_in[r] : 0.f;
@@ -104,7 +122,7 @@ __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, 
                     xh[j][i] = (xh[j][i] - mean) * rstd;
                     aw[j][i] += g[i] * xh[j][i];
                     ab[j][i] += g[i];
-                    gh[j][i] = g[i] * w[c0 + i];
+                    gh[j][i] = g[i] * wv[j][i];
                     s1 += gh[j][i];
                     s2 += gh[j][i] * xh[j][i];
                 }
