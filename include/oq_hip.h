@@ -156,6 +156,14 @@ int oq_gradnorm(const float* g, int64_t n, float* norm_out, float* workspace, vo
 int oq_adamw(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_let, float lr_let, float lr_lwc,
              float beta1, float beta2, float eps, float wd, float* step_ptr, const float* norm, void* stream);
 int oq_truncate(float* x, int64_t n, float thr, void* stream);
+/* dst[e][i] = sum_k src[e*OQ_SUM_MAX_SRC + k][i], k < nsrc[e], i < n[e], for e < entries, in one launch and in a fixed
+ * order.  Gathers the partial gradients several backward kernels produce for one shared LET parameter into the
+ * optimiser's gradient arena (what autograd's accumulation does with ~25 tiny adds behind
+ * quantize/omniquant.py:226).  The pointer tables are host arrays (copied into the kernel arguments). */
+#define OQ_SUM_MAX_ENTRIES 16
+#define OQ_SUM_MAX_SRC 6
+int oq_sum_vectors(int entries, float* const* dst, const int64_t* n, const int* nsrc, const float* const* src,
+                   void* stream);
 
 /* LET vector algebra of one block (norm weights/biases and the bias side of smooth_ln_fcs / smooth_fc_fc /
  * smooth_q_k, models/transformation.py:24-69) in one launch; all vectors f32 [n] (n = hidden size):

@@ -42,6 +42,7 @@ SIGNATURES = {
     "oq_gradnorm": [_vp, _i64, _vp, _vp, _vp],
     "oq_adamw": [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp],
     "oq_truncate": [_vp, _i64, _f32, _vp],
+    "oq_sum_vectors": [_i32, _vp, _vp, _vp, _vp, _vp],
     "oq_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
     "oq_let_vectors_fwd": [_i64] + [_vp] * 28,
     "oq_let_vectors_bwd": [_i64] + [_vp] * 39,

@@ -278,6 +278,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* x, int64_t rows, i
 extern "C" int oq_rope(const void* x, void* y, int dtype, int64_t T, int64_t heads, int64_t hd, const float* cos,
                        const float* sin, int inverse, void* stream) {
     OQ_CHECK_ARG(x && y && cos && sin, "oq_rope: null pointer");
+    OQ_CHECK_ARG(oq_aligned16(cos) && oq_aligned16(sin), "oq_rope: cos/sin tables must be 16-byte aligned");
     OQ_CHECK_ARG(T > 0 && heads > 0 && hd > 0 && hd % 16 == 0, "oq_rope: head_dim %lld must be a multiple of 16", (long long)hd);
     const int64_t nvec = T * heads * (hd / 16);
     hipStream_t st = (hipStream_t)stream;

@@ -195,6 +195,7 @@ int norm_threads(int64_t cols) {
 extern "C" int oq_norm_fwd(const void* x, int dtype, int64_t rows, int64_t cols, const float* w, const float* b,
                            float eps, int is_layernorm, void* y, float* rstd, float* mean, void* stream) {
     OQ_CHECK_ARG(x && y && w && rstd, "oq_norm_fwd: null pointer");
+    OQ_CHECK_ARG(oq_aligned16(w) && oq_aligned16(b), "oq_norm_fwd: weight / bias must be 16-byte aligned");
     OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 1024 * MAXCH, "oq_norm_fwd: cols %lld", (long long)cols);
     OQ_CHECK_ARG(!is_layernorm || mean, "oq_norm_fwd: layernorm needs mean buffer");
     const int bt = norm_threads(cols);
@@ -218,6 +219,7 @@ extern "C" int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t row
                            const float* rstd, const float* mean, int is_layernorm, void* gx, float* gw, float* gb,
                            float* workspace, int64_t workspace_floats, void* stream) {
     OQ_CHECK_ARG(x && gy && gx && w && rstd, "oq_norm_bwd: null pointer");
+    OQ_CHECK_ARG(oq_aligned16(w), "oq_norm_bwd: weight must be 16-byte aligned");
     OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 512 * MAXCH, "oq_norm_bwd: cols %lld", (long long)cols);
     int bt = norm_threads(cols);
     if (bt > 512) bt = 512;

@@ -111,6 +111,56 @@ extern "C" int oq_truncate(float* x, int64_t n, float thr, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// dst_e[i] = sum_k src_{e,k}[i] for up to OQ_SUM_MAX_ENTRIES vectors in ONE launch: gathers the partial gradients
+// that several backward kernels produced for the same shared LET parameter (q/k/v/norm all touch the qkv scale)
+// straight into the optimiser's gradient arena.  Replaces the ~25 tiny `add` launches autograd would issue for
+// that accumulation (quantize/omniquant.py:226 loss_scaler -> loss.backward()); fixed summation order.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+struct SumV {
+    float* dst[OQ_SUM_MAX_ENTRIES];
+    const float* src[OQ_SUM_MAX_ENTRIES][OQ_SUM_MAX_SRC];
+    int64_t n[OQ_SUM_MAX_ENTRIES];
+    int nsrc[OQ_SUM_MAX_ENTRIES];
+};
+
+__global__ void __launch_bounds__(256) sum_vectors_kernel(SumV p) {
+    const int e = blockIdx.y;
+    const int64_t n = p.n[e];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float a = 0.f;
+        for (int k = 0; k < p.nsrc[e]; ++k) a += p.src[e][k][i];
+        p.dst[e][i] = a;
+    }
+}
+}  // namespace
+
+extern "C" int oq_sum_vectors(int entries, float* const* dst, const int64_t* n, const int* nsrc, const float* const* src,
+                              void* stream) {
+    OQ_CHECK_ARG(entries > 0 && entries <= OQ_SUM_MAX_ENTRIES && dst && n && nsrc && src, "oq_sum_vectors: %d entries (max %d)",
+                 entries, OQ_SUM_MAX_ENTRIES);
+    SumV p{};
+    int64_t nmax = 0;
+    for (int e = 0; e < entries; ++e) {
+        OQ_CHECK_ARG(dst[e] && n[e] > 0 && nsrc[e] > 0 && nsrc[e] <= OQ_SUM_MAX_SRC, "oq_sum_vectors: entry %d: n=%lld nsrc=%d", e,
+                     (long long)n[e], nsrc[e]);
+        p.dst[e] = dst[e];
+        p.n[e] = n[e];
+        p.nsrc[e] = nsrc[e];
+        for (int k = 0; k < nsrc[e]; ++k) {
+            OQ_CHECK_ARG(src[e * OQ_SUM_MAX_SRC + k], "oq_sum_vectors: entry %d source %d is NULL", e, k);
+            p.src[e][k] = src[e * OQ_SUM_MAX_SRC + k];
+        }
+        nmax = n[e] > nmax ? n[e] : nmax;
+    }
+    int64_t gx = (nmax + 255) / 256;
+    gx = gx > 64 ? 64 : gx;
+    hipLaunchKernelGGL(sum_vectors_kernel, dim3((unsigned)gx, (unsigned)entries), dim3(256), 0, (hipStream_t)stream, p);
+    OQ_CHECK_LAUNCH("oq_sum_vectors");
+    return OQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LET vector algebra of one block in ONE launch (forward) + ONE launch (backward).
 // Replaces the [hidden]-sized eager ops of models/transformation.py:24-69 (norm weight/bias re-parameterisation and
 // the bias side of smooth_ln_fcs / smooth_fc_fc / smooth_q_k):

@@ -172,9 +172,14 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
         segi[j] = (int)((uint32_t)cc[j] / (uint32_t)p.seg);
         if constexpr (LET) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                cmv[j][i] = p.col_mul ? p.col_mul[cc[j] + i] : 1.f;
-                shv[j][i] = (valid[j] && p.shift) ? p.shift[cc[j] + i] : 0.f;
+            for (int i = 0; i < 8; ++i) { cmv[j][i] = 1.f; shv[j][i] = 0.f; }
+            if (p.col_mul) Vec8<float>::load(p.col_mul + cc[j], cmv[j]);
+            if (p.shift) {
+                Vec8<float>::load(p.shift + cc[j], shv[j]);
+                if (!valid[j]) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) shv[j][i] = 0.f;      // surplus lanes must not add to w @ shift
+                }
             }
         }
     }
@@ -371,10 +376,7 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
         cc[j] = valid[j] ? c0 : (small ? (int)(p.cols - p.seg) + (t & (lps - 1)) * 8 : (int)p.cols - 8);
         segi[j] = (int)((uint32_t)cc[j] / (uint32_t)p.seg);
         if constexpr (LET) {
-            if (p.col_mul) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) cmv[j][i] = p.col_mul[cc[j] + i];
-            }
+            if (p.col_mul) Vec8<float>::load(p.col_mul + cc[j], cmv[j]);
         }
     }
     Raw8<TIN> nw[CH];
@@ -687,7 +689,8 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     if (rc) return rc;
     OQ_CHECK_ARG(w && y, "oq_fakequant_fwd: null w/y");
     OQ_CHECK_ARG(scale && zp && xmin && xmax, "oq_fakequant_fwd: scale/zp/xmin/xmax outputs are required");
-    OQ_CHECK_ARG(oq_aligned16(w) && oq_aligned16(y), "oq_fakequant_fwd: w/y must be 16-byte aligned");
+    OQ_CHECK_ARG(oq_aligned16(w) && oq_aligned16(y) && oq_aligned16(col_mul) && oq_aligned16(shift),
+                 "oq_fakequant_fwd: w/y/col_mul/shift must be 16-byte aligned");
     OQ_CHECK_ARG((up == nullptr) == (low == nullptr), "oq_fakequant_fwd: up/low must both be given or both NULL");
     OQ_CHECK_ARG(!wshift || shift, "oq_fakequant_fwd: wshift requested without shift");
     FQ p{};
@@ -747,7 +750,8 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
     if (rc) return rc;
     OQ_CHECK_ARG(w && g, "oq_fakequant_bwd: null w/g");
     OQ_CHECK_ARG(xmin && xmax, "oq_fakequant_bwd: xmin/xmax (the forward's per-segment min/max) are required");
-    OQ_CHECK_ARG(oq_aligned16(w) && oq_aligned16(g) && oq_aligned16(gx), "oq_fakequant_bwd: 16-byte alignment");
+    OQ_CHECK_ARG(oq_aligned16(w) && oq_aligned16(g) && oq_aligned16(gx) && oq_aligned16(col_mul),
+                 "oq_fakequant_bwd: 16-byte alignment");
     OQ_CHECK_ARG(!gx || gx_dtype == g_dtype, "oq_fakequant_bwd: gx dtype must equal g dtype");
     OQ_CHECK_ARG((up == nullptr) == (low == nullptr), "oq_fakequant_bwd: up/low must both be given or both NULL");
     OQ_CHECK_ARG(!g_shift || g_wshift, "oq_fakequant_bwd: g_shift needs g_wshift");

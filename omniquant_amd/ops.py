@@ -55,6 +55,10 @@ class FakeQuantFn(torch.autograd.Function):
             stash["scale"], stash["zp"] = scale, zp
         ctx.save_for_backward(w, cm, rd, rm, sh, u, l, xmin, xmax)
         ctx.cfg = (rows, cols, seg, nbits, int(symmetric))
+        # gradient routing set up by optim.BlockOptimizer: single-use learnables (LWC bounds) get their gradient
+        # written straight into the arena, shared ones (LET vectors) go through the GradCollector
+        ctx.route = [t if (t is not None and getattr(t, "_oq_grad_sink", None) is not None and _gradient_routing_on())
+                     else None for t in (col_mul, row_div, row_mul, shift, up, low)]
         if wshift is None:
             wshift = torch.empty((0,), device=w.device)   # placeholder output, never used (no kernel launched)
             ctx.has_wshift = False
@@ -73,8 +77,11 @@ class FakeQuantFn(torch.autograd.Function):
             gy = torch.zeros(w.shape, dtype=torch.float32, device=dev)
         gy = gy.contiguous()
         nseg = rows * (cols // seg)
-        g_up = torch.empty((nseg, 1), dtype=torch.float32, device=dev) if need[5] else None
-        g_low = torch.empty((nseg, 1), dtype=torch.float32, device=dev) if need[6] else None
+        r_cm, r_rd, r_rm, r_sh, r_up, r_low = ctx.route
+        g_up = (r_up._oq_grad_sink.view(nseg, 1) if r_up is not None else
+                torch.empty((nseg, 1), dtype=torch.float32, device=dev)) if need[5] else None
+        g_low = (r_low._oq_grad_sink.view(nseg, 1) if r_low is not None else
+                 torch.empty((nseg, 1), dtype=torch.float32, device=dev)) if need[6] else None
         gx = torch.empty(w.shape, dtype=gy.dtype, device=dev) if need[0] else None
         g_cm = torch.empty((cols,), dtype=torch.float32, device=dev) if need[1] else None
         g_rd = torch.empty((rows,), dtype=torch.float32, device=dev) if need[2] else None
@@ -94,7 +101,21 @@ class FakeQuantFn(torch.autograd.Function):
                C.fptr(g_cm), C.fptr(g_sh), C.fptr(g_rd), C.fptr(g_rm), C.fptr(ws), ws_n, C.stream())
         if gx is not None and gx.dtype != w.dtype:
             gx = gx.to(w.dtype)
+        if r_up is not None:
+            g_up = None               # already in the arena
+        if r_low is not None:
+            g_low = None
+        outs = [g_cm, g_rd, g_rm, g_sh]
+        for i, (par, g) in enumerate(zip((r_cm, r_rd, r_rm, r_sh), outs)):
+            if par is not None and g is not None:
+                par._oq_collector.add(par, g)
+                outs[i] = None
+        g_cm, g_rd, g_rm, g_sh = outs
         return gx, g_cm, g_rd, g_rm, g_sh, g_up, g_low, None, None, None, None, None
+
+
+def _gradient_routing_on():
+    return not os.environ.get("OQ_NO_GRAD_ROUTING")       # A/B switch: plain autograd accumulation
 
 
 def fake_quant(x, nbits, seg=None, up=None, low=None, symmetric=False, out_dtype=None, stash=None,
@@ -521,6 +542,8 @@ class LetVectorsFn(torch.autograd.Function):
         C.call("oq_let_vectors_fwd", n, *[C.fptr(x) for x in ins], *[C.fptr(o) for o in outs], C.stream())
         ctx.save_for_backward(*[x for x in ins if x is not None])
         ctx.present = [x is not None for x in ins]
+        ctx.route = [p if (p is not None and getattr(p, "_oq_grad_sink", None) is not None and _gradient_routing_on())
+                     else None for p in (s1, h1, s2, h2, s3, h3, t)]
         return tuple(outs)
 
     @staticmethod
@@ -533,8 +556,12 @@ class LetVectorsFn(torch.autograd.Function):
         res = [torch.empty(n, dtype=torch.float32, device=dev) for _ in range(11)]
         C.call("oq_let_vectors_bwd", n, *[C.fptr(x) for x in ins], *[C.fptr(x) for x in g], *[C.fptr(x) for x in res],
                C.stream())
-        g_s1, g_h1, g_s2, g_h2, g_s3, g_h3, g_t, g_wq, g_wk, g_wv, g_wo = res
-        return (g_s1, g_h1, g_s2, g_h2, g_s3, g_h3, g_t, g_wq, g_wk, g_wv, g_wo) + (None,) * 8
+        pg = list(res[:7])
+        for i, par in enumerate(ctx.route):
+            if par is not None:
+                par._oq_collector.add(par, pg[i])      # summed into the arena by GradCollector.flush()
+                pg[i] = None
+        return tuple(pg) + tuple(res[7:]) + (None,) * 8
 
 
 def mask_is_causal(attention_mask):

@@ -8,9 +8,61 @@ contiguous float32 arena; the nn.Parameters keep their identity, names and shape
 their .grad tensors.  zero_grad = one memset, grad-norm = one reduction, AdamW = one kernel with the step
 counter and the finite-flag on the device (graph-replayable, no host sync, no loss scaling needed for bf16).
 """
+import ctypes
+
 import torch
 
 from . import _capi as C
+
+SUM_MAX_ENTRIES, SUM_MAX_SRC = 16, 6      # OQ_SUM_MAX_ENTRIES / OQ_SUM_MAX_SRC of include/oq_hip.h
+
+
+class GradCollector:
+    """Gathers the partial gradients of SHARED learnables straight into the gradient arena.
+
+    A LET vector such as qkv_smooth_scale feeds four backward kernels (the fused fake-quant of q, k and v and the
+    LET vector kernel).  Left to autograd, their four results are summed by three tiny `add` launches plus one more
+    into .grad -- 22 launches (~4.7 us each) per step for a LLaMA block.  Instead the autograd Functions of ops.py
+    hand those partial tensors to this collector (and return None to autograd), and `flush()` -- called once per
+    step, after backward -- writes grad_slot = sum(partials) for every parameter with ONE oq_sum_vectors launch, in
+    the fixed order the partials were produced.  Single-use learnables (the LWC bounds) do not come here at all:
+    their backward kernel writes into the arena directly (`_oq_grad_sink`)."""
+
+    def __init__(self):
+        self.pending = {}     # id(param) -> (grad view, [partial tensors])
+
+    def add(self, param, partial):
+        ent = self.pending.get(id(param))
+        if ent is None:
+            ent = self.pending[id(param)] = (param._oq_grad_sink, [])
+        ent[1].append(partial.contiguous().view(-1))
+
+    def flush(self):
+        if not self.pending:
+            return
+        entries = list(self.pending.values())
+        self.pending = {}
+        for i in range(0, len(entries), SUM_MAX_ENTRIES):
+            chunk = entries[i:i + SUM_MAX_ENTRIES]
+            E = len(chunk)
+            dst = (ctypes.c_void_p * E)()
+            n = (ctypes.c_int64 * E)()
+            nsrc = (ctypes.c_int * E)()
+            src = (ctypes.c_void_p * (E * SUM_MAX_SRC))()
+            keep = []
+            for e, (gview, parts) in enumerate(chunk):
+                if len(parts) > SUM_MAX_SRC:        # more partials than one launch takes: pre-sum the tail with torch
+                    head, tail = parts[:SUM_MAX_SRC - 1], parts[SUM_MAX_SRC - 1:]
+                    parts = head + [torch.stack(tail).sum(0)]
+                keep.append(parts)
+                dst[e] = C.fptr(gview.view(-1))
+                n[e] = gview.numel()
+                nsrc[e] = len(parts)
+                for k, t in enumerate(parts):
+                    if t.numel() != gview.numel():
+                        raise C.OQError("GradCollector: partial gradient has the wrong size")
+                    src[e * SUM_MAX_SRC + k] = C.fptr(t)
+            C.call("oq_sum_vectors", E, dst, n, nsrc, src, C.stream())
 
 
 class BlockOptimizer:
@@ -34,6 +86,7 @@ class BlockOptimizer:
         self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
         self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
         self._ws = torch.zeros(512, dtype=torch.float32, device=dev)
+        self.collector = GradCollector()
         off = 0
         with torch.no_grad():
             for _, p in self.named:
@@ -42,6 +95,9 @@ class BlockOptimizer:
                 p.data = self.flat[off:off + k].view(p.shape)
                 p.grad = self.grad[off:off + k].view(p.shape)
                 p.requires_grad_(True)
+                # gradient routing without autograd's accumulate kernels (ops.py reads these attributes)
+                p._oq_grad_sink = p.grad
+                p._oq_collector = self.collector
                 off += k
         if self.n_scale:
             qlayer.__dict__["_arena_truncate"] = self.truncate_scales     # block's truncate_number -> one launch
@@ -56,7 +112,12 @@ class BlockOptimizer:
         if self.n_scale:
             C.call("oq_truncate", C.fptr(self.flat), self.n_scale, float(thr), C.stream())
 
+    def collect_grads(self):
+        """Finish the backward pass: one launch sums the partial gradients of the shared learnables into the arena."""
+        self.collector.flush()
+
     def grad_norm(self):
+        self.collector.flush()
         C.call("oq_gradnorm", C.fptr(self.grad), self.n, C.fptr(self.norm), C.fptr(self._ws), C.stream())
         return self.norm[0]
 
@@ -77,6 +138,8 @@ class NativeScalerWithGradNormCount:
     def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True,
                  retain_graph=False):
         loss.backward(create_graph=create_graph, retain_graph=retain_graph)
+        if hasattr(optimizer, "collect_grads"):
+            optimizer.collect_grads()
         if not update_grad:
             return None
         if clip_grad is not None:
