@@ -123,6 +123,15 @@ int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols
                    int64_t mask_rows, int causal, void* stream);
 int oq_softmax_bwd(const void* p, const void* gp, void* gs, int dtype, int64_t rows, int64_t cols, float alpha,
                    int causal, void* stream);
+/* ---- activation statistics for the LET initialisation (generate_act_scale_shift.py:25-94), computed from the
+ *      teacher pass's activations instead of a separate offline pre-pass.  x [nsamp, rows, cols]:
+ *      scale[c] = running max over samples of max_t |x[s,t,c]|;  shift[c] = (max_t x + min_t x)/2 of the first sample,
+ *      then 0.99*shift + 0.01*(max_t x + min_t x)/2 for every further sample, applied in sample order.  `seen` = number
+ *      of samples already folded into scale/shift (0: they are overwritten). ------------------------------------- */
+int64_t oq_act_stats_workspace(int64_t nsamp, int64_t cols);
+int oq_act_stats(const void* x, int dtype, int64_t nsamp, int64_t rows, int64_t cols, float* scale, float* shift,
+                 int64_t seen, float* workspace, int64_t workspace_floats, void* stream);
+
 /* ---- fused causal attention (models/int_llama_layer.py:143-163 and its autograd; bf16, head_dim 128, exact
  *      causal mask, T == 128 or T % 256 == 0 -- oq_attn_supported() says whether a problem qualifies; everything else keeps using
  *      oq_gemm + oq_softmax_*).  q, o, go [bs,T,nh,hd]; k, v [bs,T,nkv,hd] (q/k/v already fake-quantised by the caller,

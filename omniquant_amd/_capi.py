@@ -42,6 +42,7 @@ SIGNATURES = {
     "oq_gradnorm": [_vp, _i64, _vp, _vp, _vp],
     "oq_adamw": [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp],
     "oq_truncate": [_vp, _i64, _f32, _vp],
+    "oq_act_stats": [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "oq_sum_vectors": [_i32, _vp, _vp, _vp, _vp, _vp],
     "oq_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
     "oq_let_vectors_fwd": [_i64] + [_vp] * 28,
@@ -50,7 +51,7 @@ SIGNATURES = {
 
 # functions returning a size instead of an error code
 SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64],
-              "oq_attn_supported": [_i32, _i64, _i32, _i32]}
+              "oq_attn_supported": [_i32, _i64, _i32, _i32], "oq_act_stats_workspace": [_i64, _i64]}
 
 _lib = None
 

@@ -187,10 +187,20 @@ def calibrate_block(qlayer, args, family, layer_idx, quant_inps, fp_inps, fp_inp
     nsamples = quant_inps.shape[0]
     # ---- teacher pass ----------------------------------------------------------------------------------
     qlayer.set_quant_state(weight_quant=False, act_quant=False)
-    if args.epochs > 0:
-        if args.aug_loss:
+    stat_mods, stats = [], None
+    if args.let and act_scales is None:
+        # no pre-computed statistics (generate_act_scale_shift.py was not run): gather them from the teacher pass
+        from .actstats import ActStatCollector
+        stats = ActStatCollector()
+    if args.epochs > 0 or stats is not None:
+        if args.aug_loss and args.epochs > 0:
             forward_bank(qlayer, quant_inps, fp_inps_2, mask, position_ids, is_llama, bank_chunk)
+        if stats is not None:
+            stat_mods = stats.attach(qlayer, LAYER_PREFIX[family], layer_idx, only=list(LET_PAIRS[family].keys()))
         forward_bank(qlayer, fp_inps, fp_inps, mask, position_ids, is_llama, bank_chunk)
+        if stats is not None:
+            stats.detach(stat_mods)
+            act_scales, act_shifts = stats.scales, stats.shifts
     # ---- learnables ------------------------------------------------------------------------------------
     qlayer.set_quant_state(weight_quant=False, act_quant=True)
     qlayer.let = args.let
@@ -243,7 +253,7 @@ def calibrate_block(qlayer, args, family, layer_idx, quant_inps, fp_inps, fp_inp
     for m in qlayer.modules():
         if isinstance(m, QuantLinear):
             m.drop_cache()
-    return dict(losses=losses, norms=norms, omni=omni)
+    return dict(losses=losses, norms=norms, omni=omni, act_scales=act_scales, act_shifts=act_shifts)
 
 
 def calibrate_layers(layers, config, args, inps, attention_mask, position_ids=None, act_scales=None,

@@ -63,6 +63,9 @@ class QuantLinear(nn.Module):
         return input
 
     def forward(self, input: torch.Tensor, input_is_quantized: bool = False):
+        sink = self.__dict__.get("_stat_sink")
+        if sink is not None:                        # LET-init statistics ride on the FP teacher pass (actstats.py)
+            sink[0].update(sink[1], input)
         if self.use_temporary_parameter:
             weight, bias = self.temp_weight, self.temp_bias
             ev = self.__dict__.get("_temp_ready")

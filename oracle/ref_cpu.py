@@ -123,6 +123,20 @@ def let_init_scale(act_absmax, weight, alpha):
 # ----------------------------------------------------------------------------------------------
 # block description
 # ----------------------------------------------------------------------------------------------
+def act_stats(samples):
+    """LET-init activation statistics of one linear input (generate_act_scale_shift.py:29-37,63-72).
+    samples: iterable of [..., K] tensors, one per calibration sample, IN ORDER.  Returns (act_scale[K], act_shift[K]):
+    running max of max|x| per channel; (max+min)/2 of the first sample, then 0.99*prev + 0.01*(max+min)/2."""
+    scale = shift = None
+    for x in samples:
+        t = x.reshape(-1, x.shape[-1]).detach()
+        amax = t.abs().max(dim=0)[0].float()
+        mid = (t.max(dim=0)[0].float() + t.min(dim=0)[0].float()) / 2
+        scale = amax if scale is None else torch.max(scale, amax)
+        shift = mid if shift is None else 0.99 * shift + 0.01 * mid
+    return scale, shift
+
+
 class QuantSpec:
     def __init__(self, wbits=4, abits=16, group_size=None, lwc=True, let=False, symmetric=False):
         self.wbits, self.abits, self.group_size = wbits, abits, group_size

@@ -499,7 +499,44 @@ def gen_misc():
     save("g5_misc.npz", arrays)
 
 
+def gen_act_stats():
+    """G6: the reference's own get_act_scales / get_act_shifts (generate_act_scale_shift.py:25-94) driven over a
+    tiny two-linear model and 5 'samples'; fixtures hold every hooked linear input and the resulting dicts."""
+    import generate_act_scale_shift as ref_gen      # the reference's pre-pass script (its hooks, its arithmetic)
+    g = torch.Generator().manual_seed(11)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = torch.nn.Linear(24, 40)
+            self.fc2 = torch.nn.Linear(40, 16)
+
+        def forward(self, x):
+            return self.fc2(torch.relu(self.fc1(x)) - 0.3)
+
+    model = Tiny()
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * 0.4)
+    xs = [torch.randn(1, 33, 24, generator=g) * (1 + i) for i in range(5)]
+    xs[2][0, 5, 3] = 9.5            # a large positive outlier in one sample
+    xs[3][0, 7, 4] = -12.0          # and a large negative one (abs-max must catch it)
+    dataloader = [(x,) for x in xs]
+    scales = ref_gen.get_act_scales(model, dataloader, num_samples=5)
+    shifts = ref_gen.get_act_shifts(model, dataloader, num_samples=5)
+    with torch.no_grad():
+        h = [torch.relu(model.fc1(x)) - 0.3 for x in xs]
+    arrays = dict(x_fc1=torch.cat(xs), x_fc2=torch.cat(h))
+    for k in ("fc1", "fc2"):
+        arrays[f"scale_{k}"] = scales[k]
+        arrays[f"shift_{k}"] = shifts[k]
+    save("g6_act_stats.npz", arrays)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "act_stats":
+        gen_act_stats()
+        sys.exit(0)
     gen_quantizer()
     gen_misc()
     # (family, tag, wbits, abits, group, lwc, let)
@@ -514,3 +551,4 @@ if __name__ == "__main__":
     gen_trajectory(True, "w2a16g16_lwc_aug", 2, 16, 16, True, False, aug_loss=True)
     gen_trajectory(False, "w4a16_lwc", 4, 16, None, True, False)
     gen_trajectory(False, "w4a4_lwc_let", 4, 4, None, True, True)
+    gen_act_stats()

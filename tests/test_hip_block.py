@@ -116,3 +116,39 @@ def test_sharded_engine_single_rank_matches_sequential():
             ref = g[k].astype(np.float64)
             got = merged[i][n].double().numpy()
             assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6) + 1e-3, (i, n)
+
+
+def test_let_init_statistics_from_teacher_pass():
+    """calibrate_block without pre-computed act_scales/act_shifts: the statistics gathered while the FP teacher pass
+    streams the bank must equal the oracle's restatement of generate_act_scale_shift.py applied to the same linear
+    inputs, and the LET parameters initialised from them must match the formula of quantize/omniquant.py:189-191."""
+    from omniquant_amd.calibrate import calibrate_block, default_args, LAYER_PREFIX
+    from omniquant_amd.synthetic import make_config, make_layer, make_calib_inputs, causal_mask
+    from omniquant_amd.llama_block import QuantLlamaDecoderLayer
+    from oracle import ref_cpu as R
+    cfg = make_config(None, family="llama", hidden_size=256, inter=512, heads=2, kv_heads=2)
+    args = default_args(wbits=4, abits=4, lwc=True, let=True, epochs=0, nsamples=6, net="llama")
+    layer = make_layer(cfg, seed=3, device=DEV)
+    w = layer.input_layernorm.weight.detach().float().cpu().clone()          # before the final fold rewrites them
+    wq = layer.self_attn.q_proj.weight.detach().float().cpu().clone()
+    eps = layer.input_layernorm.variance_epsilon
+    q = QuantLlamaDecoderLayer(cfg, layer, args).to(DEV)
+    T = 64
+    x = make_calib_inputs(6, T, 256, dtype=torch.float32).to(DEV)
+    fp = x.clone()
+    mask = causal_mask(T).to(DEV)
+    pos = torch.arange(T, device=DEV)[None]
+    res = calibrate_block(q, args, "llama", 0, x.clone(), fp, None, mask, pos, None, None, compute_dtype=torch.float32,
+                          use_graph=False, bank_chunk=4)
+    sc, sh = res["act_scales"], res["act_shifts"]
+    key = f"{LAYER_PREFIX['llama']}.0.self_attn.q_proj"
+    assert set(k.rsplit(".", 1)[1] for k in sc) == {"q_proj", "o_proj", "up_proj"}
+    # the q_proj input is the RMSNorm output of the teacher input: recompute it on the CPU in fp32
+    xc = x.cpu()
+    h = xc * torch.rsqrt(xc.pow(2).mean(-1, keepdim=True) + eps) * w
+    sc_ref, sh_ref = R.act_stats([h[i:i + 1] for i in range(6)])
+    np.testing.assert_allclose(sc[key].cpu().numpy(), sc_ref.numpy(), rtol=2e-5)
+    np.testing.assert_allclose(sh[key].cpu().numpy(), sh_ref.numpy(), rtol=2e-4, atol=2e-6)
+    want = R.let_init_scale(sc[key].cpu(), wq, 0.5)
+    got = q.qkv_smooth_scale.detach().float().cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-3)      # parameters were cast to fp16 by .half()

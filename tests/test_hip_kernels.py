@@ -427,3 +427,30 @@ def test_fused_causal_attention(Tn, nh, nkv):
         err_u = float((u.detach().double().cpu() - r).abs().max()) / sc
         assert err < 2e-2, f"fused {name}: {err} (unfused path: {err_u})"
         assert err < 2.0 * err_u + 4e-3, f"fused {name} is less accurate than the unfused kernels: {err} vs {err_u}"
+
+
+def test_act_stats_kernel_vs_golden_and_oracle():
+    """oq_act_stats (LET-init statistics fused into the teacher pass) vs the reference's own
+    generate_act_scale_shift.py functions (G6 fixture, rows padded to the kernel's 32-row minimum by replaying whole
+    samples) and vs the oracle at the full [4, 2048, 4096] bf16 size fed in two chunks (bit-exact: max/min/abs are
+    exact, the running average is the same fp32 expression in the same order)."""
+    from omniquant_amd.actstats import ActStatCollector
+    from oracle import ref_cpu as R
+    g, _ = load_golden("g6_act_stats.npz")
+    for k in ("fc1", "fc2"):
+        x = torch.from_numpy(g[f"x_{k}"])                       # [5, 33, K] fp32
+        col = ActStatCollector()
+        col.update(k, x[:2].to(DEV))                            # chunked, as the engine's forward_bank does
+        col.update(k, x[2:].to(DEV))
+        np.testing.assert_array_equal(col.scales[k].cpu().numpy(), g[f"scale_{k}"])
+        np.testing.assert_array_equal(col.shifts[k].cpu().numpy(), g[f"shift_{k}"])
+    gen = torch.Generator().manual_seed(3)
+    big = (torch.randn(4, 2048, 4096, generator=gen) * torch.exp(0.5 * torch.randn(4096, generator=gen))).to(torch.bfloat16)
+    col = ActStatCollector()
+    col.update("a", big[:3].to(DEV))
+    col.update("a", big[3:].to(DEV))
+    sc, sh = R.act_stats([big[i:i + 1] for i in range(4)])
+    np.testing.assert_array_equal(col.scales["a"].cpu().numpy(), sc.numpy())
+    np.testing.assert_array_equal(col.shifts["a"].cpu().numpy(), sh.numpy())
+    with pytest.raises(Exception):
+        col.update("cpu", torch.randn(2, 64, 64))               # no CPU fallback

@@ -144,3 +144,13 @@ def test_trajectory(fname):
             tol = 1e-3 * max(np.abs(ref).max(), 1e-6)
             assert np.abs(got - ref).max() <= tol + 1e-3 * 0, f"{n}: {np.abs(got-ref).max()} > {tol}"
         close(res["quant_out"][i], g[f"quant_out.{i}"], rtol=5e-2, atol=5e-2, what=f"quant_out {i}")
+
+
+def test_act_stats_vs_reference_prepass():
+    """G6: oracle restatement of generate_act_scale_shift.py:25-94 vs the reference's own functions (bit-exact)."""
+    g, _ = load_golden("g6_act_stats.npz")
+    for k in ("fc1", "fc2"):
+        x = torch.from_numpy(g[f"x_{k}"])
+        sc, sh = R.act_stats([x[i:i + 1] for i in range(x.shape[0])])
+        np.testing.assert_array_equal(sc.numpy(), g[f"scale_{k}"])
+        np.testing.assert_array_equal(sh.numpy(), g[f"shift_{k}"])
