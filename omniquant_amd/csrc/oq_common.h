@@ -173,7 +173,11 @@ OQ_WAVE_REDUCE(wave_min, vmin)
 __device__ __forceinline__ float nmax(float a, float b) { return (a != a) ? a : ((b != b) ? b : fmaxf(a, b)); }
 __device__ __forceinline__ float nmin(float a, float b) { return (a != a) ? a : ((b != b) ? b : fminf(a, b)); }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// 1 / (1 + e^-x) on the hardware transcendental units (v_exp_f32 = 2^x, v_rcp_f32; ~2 ulp): two of these run per row
+// and per lane of the quantiser kernels, the OCML expf + IEEE divide expansion was ~35 instructions each.
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 
 // Raw v_max_f32 / v_min_f32: fmaxf/fminf compile to canonicalise + max (3 VALU ops); the single instruction returns
 // the non-NaN operand exactly like fmaxf (IEEE maxNum) and is all the hot loops need.

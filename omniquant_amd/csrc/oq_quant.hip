@@ -34,8 +34,19 @@ struct FQ {
 };
 
 // block-wide reduction of up to 3 values; op: 0 sum, 1 max, 2 min.  All threads must call.
+// block-wide reduction of up to 4 values; op: 0 sum, 1 max, 2 min.  All threads must call.  The cross-wave step reads
+// the (at most 8) per-wave partials of a value with one or two ds_read_b128 and combines them unconditionally: slots of
+// waves that do not exist hold the operation's identity (written once by red_init), so there is no runtime loop.
+// Every call site owns its `red` region (the identities are per operation).
+__device__ __forceinline__ float red_identity(int op) { return op == 0 ? 0.f : (op == 1 ? -INFINITY : INFINITY); }
+
 template <int NV>
-__device__ __forceinline__ void block_reduce(float (&v)[NV], const int (&op)[NV], float* red /*[NV*16]*/,
+__device__ __forceinline__ void red_init(const int (&op)[NV], float* red /*[NV*8]*/) {
+    if (threadIdx.x < NV * 8) red[threadIdx.x] = red_identity(op[threadIdx.x >> 3]);
+}
+
+template <int NV>
+__device__ __forceinline__ void block_reduce(float (&v)[NV], const int (&op)[NV], float* red /*[NV*8], red_init'ed*/,
                                              unsigned wave_uniform = 0 /* bit i: v[i] is already a per-wave value */) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
 #pragma unroll
@@ -47,17 +58,23 @@ __device__ __forceinline__ void block_reduce(float (&v)[NV], const int (&op)[NV]
     __syncthreads();   // protect `red` from the previous use
     if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) red[i * 16 + wid] = v[i];
+        for (int i = 0; i < NV; ++i) red[i * 8 + wid] = v[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        float a = red[i * 16];
-        for (int k = 1; k < nw; ++k) {
-            float b = red[i * 16 + k];
-            a = op[i] == 0 ? a + b : (op[i] == 1 ? fmaxf(a, b) : fminf(a, b));
+        const f32x4 a = *reinterpret_cast<const f32x4*>(red + i * 8);
+        float r;
+        if (op[i] == 0) r = (a[0] + a[1]) + (a[2] + a[3]);
+        else if (op[i] == 1) r = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+        else r = fminf(fminf(a[0], a[1]), fminf(a[2], a[3]));
+        if (nw > 4) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(red + i * 8 + 4);
+            if (op[i] == 0) r += (b[0] + b[1]) + (b[2] + b[3]);
+            else if (op[i] == 1) r = fmaxf(r, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+            else r = fminf(r, fminf(fminf(b[0], b[1]), fminf(b[2], b[3])));
         }
-        v[i] = a;
+        v[i] = r;
     }
 }
 
@@ -150,12 +167,20 @@ __device__ __forceinline__ QP make_qp(float hi, float lo, bool lwc, float up_log
 // (vmcnt(N)), not for the previous row's stores to be acknowledged (vmcnt(0), a full memory round trip per row).
 template <typename TIN, typename TOUT, bool LET, int CH, bool FULL>
 __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
-    __shared__ float red[3 * 16];
+    __shared__ __attribute__((aligned(16))) float red[4 * 8 + 8];
     const int t = threadIdx.x, BT = blockDim.x;
     const bool small = p.seg <= 512;
     const int lps = small ? (int)(p.seg >> 3) : 64;
     const int64_t nseg = p.cols / p.seg;
     const float Q = (float)((1 << p.nbits) - 1);
+    {
+        const int op0[4] = {1, 2, 1, 0};
+        const int op1[1] = {0};
+        red_init<4>(op0, red);
+        if (threadIdx.x >= 32 && threadIdx.x < 40) red[threadIdx.x] = 0.f;      // region of the short-segment w@shift sum
+        (void)op1;
+        __syncthreads();
+    }
     const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
 
@@ -250,8 +275,9 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
                 lo[j] = vmin(lo[j], x[j][i]);
                 nanm |= __builtin_amdgcn_fcmpf(x[j][i], x[j][i], 8);       // FCMP_UNO
             }
-            bad[j] = ((nanm >> (threadIdx.x & 63)) & 1) ? 1.f : 0.f;
+            bad[j] = small ? (((nanm >> (threadIdx.x & 63)) & 1) ? 1.f : 0.f) : (nanm != 0 ? 1.f : 0.f);
         }
+        bool dot_done = false;
         if (small) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
@@ -260,17 +286,20 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
                 bad[j] = wave_max(bad[j], lps);
             }
         } else {
-            float v[3] = {-INFINITY, INFINITY, 0.f};
+            // ONE exchange per row: max, min, NaN flag (already per wave) and the w @ shift partial sum
+            float v[4] = {-INFINITY, INFINITY, 0.f, dot};
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 v[0] = fmaxf(v[0], hi[j]);
                 v[1] = fminf(v[1], lo[j]);
                 v[2] = fmaxf(v[2], bad[j]);
             }
-            const int op[3] = {1, 2, 1};
-            block_reduce<3>(v, op, red);
+            const int op[4] = {1, 2, 1, 0};
+            block_reduce<4>(v, op, red, 0x4u);
 #pragma unroll
             for (int j = 0; j < CH; ++j) { hi[j] = v[0]; lo[j] = v[1]; bad[j] = v[2]; }
+            dot = v[3];
+            dot_done = true;
         }
         // ---- quantise ---------------------------------------------------------------------------
         QP q;
@@ -326,10 +355,13 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
             }
         }
         if (LET && p.wshift) {
-            float v[1] = {dot};
-            const int op[1] = {0};
-            block_reduce<1>(v, op, red);
-            if (t == 0) p.wshift[r] = v[0];
+            if (!dot_done) {
+                float v[1] = {dot};
+                const int op[1] = {0};
+                block_reduce<1>(v, op, red + 32);
+                dot = v[0];
+            }
+            p.wshift[r] = dot;        // same value from every lane
         }
     }
 }
@@ -345,12 +377,14 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
 //   g_row_div = -(rm / rd) * g_row_mul
 template <typename TIN, typename TG, bool LET, int CH, bool FULL>
 __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
-    __shared__ float red[4 * 16];
+    __shared__ __attribute__((aligned(16))) float red[4 * 8 + 8];
     const int t = threadIdx.x, BT = blockDim.x;
     const bool small = p.seg <= 512;
     const int lps = small ? (int)(p.seg >> 3) : 64;
     const int64_t nseg = p.cols / p.seg;
     const float Q = (float)((1 << p.nbits) - 1);
+    if (threadIdx.x < 40) red[threadIdx.x] = 0.f;       // every reduction of this kernel is a sum: identity 0
+    __syncthreads();
     const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
     const TG* gbase = reinterpret_cast<const TG*>(p.g);
     TG* gxbase = reinterpret_cast<TG*>(p.gx);
@@ -565,7 +599,7 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
             if (need_row && small) {
                 float v[1] = {acc_rm + row_tie / rm};
                 const int op[1] = {0};
-                block_reduce<1>(v, op, red);
+                block_reduce<1>(v, op, red + 32);
                 if (t == 0) {
                     if (p.g_row_mul) p.g_row_mul[r] = v[0];
                     if (p.g_row_div) p.g_row_div[r] = -rmrd * v[0];
