@@ -8,6 +8,7 @@
 // registers across the rows a workgroup walks (lane -> column mapping is fixed) and flushed with one float
 // atomic per column per workgroup.
 #include <stdlib.h>
+#include <type_traits>
 #include "oq_common.h"
 
 namespace {
@@ -440,6 +441,7 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
     };
     int64_t r = blockIdx.x;
     if (r < p.rows) prefetch(r);
+#pragma unroll 2
     for (; r < p.rows; r += gridDim.x) {
         float w[CH][8], x[CH][8], G[CH][8], cup[CH], clow[CH], hi[CH], lo[CH];
         const float rd = nrd, rm = nrm, gws = ngws;
@@ -475,43 +477,49 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
             // (round(t) - t) + t, which equals rint(t) for every finite t
             const bool regular = qp[j].s != 0.f && fabsf(qp[j].s) <= 3.4028234663852886e38f;
             const uint64_t vmask = FULL ? ~0ull : __builtin_amdgcn_ballot_w64(valid[j]);
+            auto element_pass = [&](auto reg_tag) {
+                constexpr bool REG = decltype(reg_tag)::value;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v = w[j][i];
-                if constexpr (LET) {
-                    if (p.col_mul) v = v * cmv[j][i];
-                    if (p.row_div) v = div_nr(v, rd, inv_rd);   // same function as the forward: x is bit-identical
-                    if (p.row_mul) v = v * rm;                  // (ties with hi/lo and the clip mask depend on it)
-                }
-                x[j][i] = v;
-                const float tq = v * inv_s[j];
-                const float u = (regular ? rintf(tq) : rne_ste(tq)) + z;
-                const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
-                const bool in = qv == u;                        // inside [0, Q] (false for NaN)
-                // block-wide sums (whole-row segments, row factors) skip the surplus lanes; group-wide sums of the
-                // short-segment mode do not: a surplus GROUP recomputes the last segment completely
-                const float Gr = FULL ? G[j][i] : G[j][i] * live;
-                const float Gg = (FULL || small) ? G[j][i] : Gr;
-                gs[j] = fmaf(Gg, (qv - z) - (in ? tq : 0.f), gs[j]);
-                if (small) {
-                    chi[j] += (v == hi[j]) ? 1 : 0;
-                    clo[j] += (v == lo[j]) ? 1 : 0;
-                } else {
-                    // whole-row segments: one v_cmp per element, counted per wave on the scalar unit
-                    whi += __builtin_popcountll(__builtin_amdgcn_fcmpf(v, hi[j], 1) & vmask);      // FCMP_OEQ
-                    wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(v, lo[j], 1) & vmask);
-                }
-                gin[j][i] = in ? G[j][i] : 0.f;
-                if constexpr (LET) {
-                    const float gi = in ? Gr : 0.f;
-                    if (need_row) {
-                        const float b = (w[j][i] * cmv[j][i]) * inv_rd;     // x = b * rm
-                        acc_rm = fmaf(gi, b, acc_rm);
+                for (int i = 0; i < 8; ++i) {
+                    float v = w[j][i];
+                    if constexpr (LET) {
+                        if (p.col_mul) v = v * cmv[j][i];
+                        if (p.row_div) v = div_nr(v, rd, inv_rd);   // same function as the forward: x is bit-identical
+                        if (p.row_mul) v = v * rm;                  // (ties with hi/lo and the clip mask depend on it)
                     }
-                    if (need_cm) acc_cm[j][i] = fmaf(gi * rmrd, w[j][i], acc_cm[j][i]);
-                    if (need_sh) acc_sh[j][i] = fmaf(gws, w[j][i], acc_sh[j][i]);
+                    x[j][i] = v;
+                    const float tq = v * inv_s[j];
+                    const float u = (REG ? rintf(tq) : rne_ste(tq)) + z;
+                    const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
+                    const bool in = qv == u;                        // inside [0, Q] (false for NaN)
+                    // block-wide sums (whole-row segments, row factors) skip the surplus lanes; group-wide sums of the
+                    // short-segment mode do not: a surplus GROUP recomputes the last segment completely
+                    const float Gr = FULL ? G[j][i] : G[j][i] * live;
+                    const float Gg = (FULL || small) ? G[j][i] : Gr;
+                    gs[j] = fmaf(Gg, (qv - z) - (in ? tq : 0.f), gs[j]);
+                    if (small) {
+                        chi[j] += (v == hi[j]) ? 1 : 0;
+                        clo[j] += (v == lo[j]) ? 1 : 0;
+                    } else {
+                        // whole-row segments: one v_cmp per element, counted per wave on the scalar unit
+                        whi += __builtin_popcountll(__builtin_amdgcn_fcmpf(v, hi[j], 1) & vmask);      // FCMP_OEQ
+                        wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(v, lo[j], 1) & vmask);
+                    }
+                    gin[j][i] = in ? G[j][i] : 0.f;
+                    if constexpr (LET) {
+                        const float gi = in ? Gr : 0.f;
+                        if (need_row) {
+                            const float b = (w[j][i] * cmv[j][i]) * inv_rd;     // x = b * rm
+                            acc_rm = fmaf(gi, b, acc_rm);
+                        }
+                        if (need_cm) acc_cm[j][i] = fmaf(gi * rmrd, w[j][i], acc_cm[j][i]);
+                        if (need_sh) acc_sh[j][i] = fmaf(gws, w[j][i], acc_sh[j][i]);
+                    }
                 }
-            }
+            };
+            // wave-uniform choice: every lane's segment is regular (the normal case) -> plain rint in the hot loop
+            if (__builtin_amdgcn_ballot_w64(!regular) == 0) element_pass(std::true_type{});
+            else element_pass(std::false_type{});
         }
         float nhi[CH], nlo[CH];
         bool wave_tie;
