@@ -88,8 +88,11 @@ int oq_gemm(const void* a, const void* bm, void* c, const float* bias,
             int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
             int64_t sc_o, int64_t sc_i, int tri_mode, void* stream);
 
-/* column sums: out[n] = sum_m x[m,n]  (bias gradients).  out f32, zeroed by the callee. */
-int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, float* out, void* stream);
+/* column sums: out[n] = sum_m x[m,n]  (bias gradients).  out f32, overwritten.  Deterministic (slab partials in the
+ * workspace, added in slab order; no atomics).  cols % 8 == 0. */
+int64_t oq_colsum_workspace(int64_t rows, int64_t cols);
+int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, float* out, float* workspace,
+              int64_t workspace_floats, void* stream);
 
 /* ---- OmniLlamaRMSNorm / OmniLayerNorm (quantize/omni_norm.py:26-34, :52-63) -----------------------------
  * rms:  y = w * x * rsqrt(mean(x^2)+eps) (+ b);   layer: y = w * (x-mean)/sqrt(var+eps) + b.   w,b f32.

@@ -24,7 +24,7 @@ SIGNATURES = {
                          _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_gemm": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
-    "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp],
+    "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp],
     "oq_norm_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "oq_norm_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_rope": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
@@ -51,7 +51,8 @@ SIGNATURES = {
 
 # functions returning a size instead of an error code
 SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64],
-              "oq_attn_supported": [_i32, _i64, _i32, _i32], "oq_act_stats_workspace": [_i64, _i64]}
+              "oq_attn_supported": [_i32, _i64, _i32, _i32], "oq_act_stats_workspace": [_i64, _i64],
+              "oq_colsum_workspace": [_i64, _i64]}
 
 _lib = None
 

@@ -103,22 +103,21 @@ template <bool DIAG>
 __device__ __forceinline__ void fwd_tile(const char* Ks, const char* Vs, const bf16x8 (&qf)[2][4], f32x4 (&o)[2][8],
                                          float (&m)[2], float (&l)[2], const int (&dq)[2], float c2, int lane) {
     f32x4 st[4][2];
-    bf16x8 kf[2][4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kf[0][ks] = frag_row(Ks, 0, ks, lane);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-        if (kb < 3) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[(kb + 1) & 1][ks] = frag_row(Ks, 16 * (kb + 1), ks, lane);
-        }
         st[kb][0] = f32x4{0.f, 0.f, 0.f, 0.f};
         st[kb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // d-step outermost: the 8 accumulators (4 key blocks x 2 query blocks) are independent, so consecutive MFMAs never
+    // wait on each other (a key-block-outer order chains 4 dependent MFMAs per accumulator back to back)
+    bf16x8 kf[2];
+    kf[0] = frag_row(Ks, 0, 0, lane);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            st[kb][0] = MFMA(kf[kb & 1][ks], qf[0][ks], st[kb][0]);     // S^T block: row = key 16kb+4g+i, col = query
-            st[kb][1] = MFMA(kf[kb & 1][ks], qf[1][ks], st[kb][1]);
-        }
+    for (int it = 0; it < 16; ++it) {
+        const int ks = it >> 2, kb = it & 3, nx = it + 1;
+        if (nx < 16) kf[nx & 1] = frag_row(Ks, 16 * (nx & 3), nx >> 2, lane);
+        st[kb][0] = MFMA(kf[it & 1], qf[0][ks], st[kb][0]);     // S^T block: row = key 16kb+4g+i, col = query
+        st[kb][1] = MFMA(kf[it & 1], qf[1][ks], st[kb][1]);
     }
     bf16x8 vf[2];
     vf[0] = frag_tr(Vs, 0, 0, lane);             // in flight under the softmax arithmetic
@@ -298,9 +297,10 @@ __device__ __forceinline__ void bwd_phase1(const char* Qs, const char* Gs, const
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(d_s + 16 * qb + 4 * g);
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s = MFMA(qa[ks], kf[ks], s);        // row = query 16qb+4g+i, col = key
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dp = MFMA(ga[ks], vf[ks], dp);
+        for (int ks = 0; ks < 4; ++ks) {        // the two accumulation chains alternate: no back-to-back dependent MFMAs
+            s = MFMA(qa[ks], kf[ks], s);        // row = query 16qb+4g+i, col = key
+            dp = MFMA(ga[ks], vf[ks], dp);
+        }
         f32x4 pv, sv;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -242,25 +242,44 @@ __global__ void cast_kernel(const TS* x, TD* y, int64_t n) {
     }
 }
 
-__global__ void zero_f32_kernel(float* p, int64_t n) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+
+// column sums (bias gradients), deterministic: grid (column groups of 512, row slabs); a lane owns 8 columns (16-byte
+// loads), the 4 waves of a block interleave the slab's rows and combine through LDS; slab partials go to the workspace
+// and colsum_final_kernel adds them in slab order (no atomics: the order of a float sum must not depend on timing).
+constexpr int COLSUM_MAX_SLABS = 64;
+
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const T* x, int64_t rows, int64_t cols, float* ws) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t c0 = (int64_t)blockIdx.x * 512 + lane * 8;
+    const int64_t r0 = rows * blockIdx.y / gridDim.y, r1 = rows * (blockIdx.y + 1) / gridDim.y;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    if (c0 < cols) {
+        for (int64_t r = r0 + wid; r < r1; r += 4) {
+            float v[8];
+            Vec8<T>::load(x + r * cols + c0, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[wid][lane * 8 + i] = acc[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int64_t col = (int64_t)blockIdx.x * 512 + c;
+        if (col < cols) ws[(int64_t)blockIdx.y * cols + col] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
 }
 
-// column sums: block handles 64 columns x a slab of rows; lanes along columns (coalesced), then atomics
-template <typename T>
-__global__ void __launch_bounds__(256) colsum_kernel(const T* x, int64_t rows, int64_t cols, float* out) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
-    const int64_t rows_per = (rows + gridDim.y - 1) / gridDim.y;
-    const int64_t r0 = (int64_t)blockIdx.y * rows_per;
-    const int64_t r1 = r0 + rows_per < rows ? r0 + rows_per : rows;
-    float acc = 0.f;
-    if (c < cols)
-        for (int64_t r = r0 + wid; r < r1; r += 4) acc += ld1(x + r * cols + c);
-    red[wid][lane] = acc;
-    __syncthreads();
-    if (wid == 0 && c < cols) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float* ws, int slabs, int64_t cols, float* out) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float a = 0.f;
+    for (int k = 0; k < slabs; ++k) a += ws[(int64_t)k * cols + c];
+    out[c] = a;
 }
 
 }  // namespace
@@ -381,15 +400,31 @@ extern "C" int oq_cast(const void* x, int src_dtype, void* y, int dst_dtype, int
     return OQ_OK;
 }
 
-extern "C" int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, float* out, void* stream) {
-    OQ_CHECK_ARG(x && out && rows > 0 && cols > 0, "oq_colsum: bad args");
+static int colsum_slabs(int64_t rows) {
+    int64_t s = rows / 32;
+    return (int)(s < 1 ? 1 : (s > COLSUM_MAX_SLABS ? COLSUM_MAX_SLABS : s));
+}
+
+extern "C" int64_t oq_colsum_workspace(int64_t rows, int64_t cols) { return (int64_t)colsum_slabs(rows) * cols; }
+
+extern "C" int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, float* out, float* workspace,
+                         int64_t workspace_floats, void* stream) {
+    OQ_CHECK_ARG(x && out && workspace && rows > 0 && cols > 0 && cols % 8 == 0, "oq_colsum: bad args (cols %% 8 == 0)");
+    OQ_CHECK_ARG(oq_aligned16(x), "oq_colsum: x must be 16-byte aligned");
+    const int slabs = colsum_slabs(rows);
+    OQ_CHECK_ARG(workspace_floats >= (int64_t)slabs * cols, "oq_colsum: workspace of %lld floats needed",
+                 (long long)((int64_t)slabs * cols));
     hipStream_t st = (hipStream_t)stream;
-    // zeroed with a kernel, not hipMemsetAsync: a memset issued from inside the library was observed NOT to be
-    // re-executed when the enclosing stream capture is replayed as a hipGraph (stale sums on the 2nd replay)
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, out, cols);
-    int64_t gy = rows / 64; gy = gy < 1 ? 1 : (gy > 64 ? 64 : gy);
-    const dim3 grid((unsigned)((cols + 63) / 64), (unsigned)gy);
-    DT_SWITCH("oq_colsum", dtype,
-              hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, cols, out),
-              hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, rows, cols, out));
+    const dim3 grid((unsigned)((cols + 511) / 512), (unsigned)slabs);
+    if (dtype == OQ_F32)
+        hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, cols, workspace);
+    else if (dtype == OQ_BF16)
+        hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, rows, cols, workspace);
+    else {
+        oq_set_error("oq_colsum: dtype %d unsupported", dtype);
+        return OQ_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, workspace, slabs, cols, out);
+    OQ_CHECK_LAUNCH("oq_colsum");
+    return OQ_OK;
 }

@@ -193,7 +193,9 @@ class LinearFn(torch.autograd.Function):
             gemm(gy2, x2, gw, N, K, T, N, K, K, False, False)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.empty((N,), dtype=torch.float32, device=x2.device)
-            C.call("oq_colsum", C.ptr(gy2), C.dt(gy2), T, N, C.fptr(gb), C.stream())
+            ws_n = C.size_call("oq_colsum_workspace", T, N)
+            ws = torch.empty(ws_n, dtype=torch.float32, device=gy2.device)
+            C.call("oq_colsum", C.ptr(gy2), C.dt(gy2), T, N, C.fptr(gb), C.fptr(ws), ws_n, C.stream())
         return gx, gw, gb
 
 
