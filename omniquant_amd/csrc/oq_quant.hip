@@ -477,45 +477,73 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
             // (round(t) - t) + t, which equals rint(t) for every finite t
             const bool regular = qp[j].s != 0.f && fabsf(qp[j].s) <= 3.4028234663852886e38f;
             const uint64_t vmask = FULL ? ~0ull : __builtin_amdgcn_ballot_w64(valid[j]);
+            // Elements are processed in PAIRS on packed-f32 arithmetic (v_pk_mul/add/fma_f32: two lanes-worth per
+            // instruction at full rate) -- these kernels are VALU-issue-bound, not HBM-bound.
             auto element_pass = [&](auto reg_tag) {
                 constexpr bool REG = decltype(reg_tag)::value;
+                const f32x2 z2 = {z, z}, is2 = {inv_s[j], inv_s[j]}, rd2 = {rd, rd}, ird2 = {inv_rd, inv_rd}, rm2 = {rm, rm};
+                const f32x2 rmrd2 = {rmrd, rmrd}, gws2 = {gws, gws}, live2 = {live, live};
+                f32x2 gs2 = {0.f, 0.f}, arm2 = {0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float v = w[j][i];
+                for (int i = 0; i < 8; i += 2) {
+                    const f32x2 wv = {w[j][i], w[j][i + 1]};
+                    const f32x2 gv = {G[j][i], G[j][i + 1]};
+                    f32x2 v = wv, a2 = wv;
                     if constexpr (LET) {
-                        if (p.col_mul) v = v * cmv[j][i];
-                        if (p.row_div) v = div_nr(v, rd, inv_rd);   // same function as the forward: x is bit-identical
-                        if (p.row_mul) v = v * rm;                  // (ties with hi/lo and the clip mask depend on it)
+                        if (p.col_mul) { const f32x2 cm2 = {cmv[j][i], cmv[j][i + 1]}; v = v * cm2; a2 = v; }
+                        if (p.row_div) {                               // div_nr pairwise: same values as the forward
+                            const f32x2 q0 = v * ird2;
+                            const f32x2 r0 = __builtin_elementwise_fma(-q0, rd2, v);
+                            v = __builtin_elementwise_fma(r0, ird2, q0);
+                        }
+                        if (p.row_mul) v = v * rm2;                    // (ties with hi/lo and the clip mask depend on it)
                     }
-                    x[j][i] = v;
-                    const float tq = v * inv_s[j];
-                    const float u = (REG ? rintf(tq) : rne_ste(tq)) + z;
-                    const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
-                    const bool in = qv == u;                        // inside [0, Q] (false for NaN)
+                    x[j][i] = v[0];
+                    x[j][i + 1] = v[1];
+                    const f32x2 tq = v * is2;
+                    f32x2 rr;
+                    rr[0] = REG ? rintf(tq[0]) : rne_ste(tq[0]);
+                    rr[1] = REG ? rintf(tq[1]) : rne_ste(tq[1]);
+                    const f32x2 u = rr + z2;
+                    f32x2 qv;
+                    qv[0] = __builtin_amdgcn_fmed3f(u[0], 0.f, Q);
+                    qv[1] = __builtin_amdgcn_fmed3f(u[1], 0.f, Q);
+                    const bool in0 = qv[0] == u[0], in1 = qv[1] == u[1];      // inside [0, Q] (false for NaN)
                     // block-wide sums (whole-row segments, row factors) skip the surplus lanes; group-wide sums of the
                     // short-segment mode do not: a surplus GROUP recomputes the last segment completely
-                    const float Gr = FULL ? G[j][i] : G[j][i] * live;
-                    const float Gg = (FULL || small) ? G[j][i] : Gr;
-                    gs[j] = fmaf(Gg, (qv - z) - (in ? tq : 0.f), gs[j]);
+                    const f32x2 Gr = FULL ? gv : gv * live2;
+                    const f32x2 Gg = (FULL || small) ? gv : Gr;
+                    const f32x2 tsel = {in0 ? tq[0] : 0.f, in1 ? tq[1] : 0.f};
+                    gs2 = __builtin_elementwise_fma(Gg, (qv - z2) - tsel, gs2);
                     if (small) {
-                        chi[j] += (v == hi[j]) ? 1 : 0;
-                        clo[j] += (v == lo[j]) ? 1 : 0;
+                        chi[j] += ((v[0] == hi[j]) ? 1 : 0) + ((v[1] == hi[j]) ? 1 : 0);
+                        clo[j] += ((v[0] == lo[j]) ? 1 : 0) + ((v[1] == lo[j]) ? 1 : 0);
                     } else {
                         // whole-row segments: one v_cmp per element, counted per wave on the scalar unit
-                        whi += __builtin_popcountll(__builtin_amdgcn_fcmpf(v, hi[j], 1) & vmask);      // FCMP_OEQ
-                        wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(v, lo[j], 1) & vmask);
+                        whi += __builtin_popcountll(__builtin_amdgcn_fcmpf(v[0], hi[j], 1) & vmask);      // FCMP_OEQ
+                        whi += __builtin_popcountll(__builtin_amdgcn_fcmpf(v[1], hi[j], 1) & vmask);
+                        wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(v[0], lo[j], 1) & vmask);
+                        wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(v[1], lo[j], 1) & vmask);
                     }
-                    gin[j][i] = in ? G[j][i] : 0.f;
+                    gin[j][i] = in0 ? gv[0] : 0.f;
+                    gin[j][i + 1] = in1 ? gv[1] : 0.f;
                     if constexpr (LET) {
-                        const float gi = in ? Gr : 0.f;
-                        if (need_row) {
-                            const float b = (w[j][i] * cmv[j][i]) * inv_rd;     // x = b * rm
-                            acc_rm = fmaf(gi, b, acc_rm);
+                        const f32x2 gi = {in0 ? Gr[0] : 0.f, in1 ? Gr[1] : 0.f};
+                        if (need_row) arm2 = __builtin_elementwise_fma(gi, a2 * ird2, arm2);     // b = (w*cm)/rd, x = b*rm
+                        if (need_cm) {
+                            const f32x2 acc = __builtin_elementwise_fma(gi * rmrd2, wv, f32x2{acc_cm[j][i], acc_cm[j][i + 1]});
+                            acc_cm[j][i] = acc[0];
+                            acc_cm[j][i + 1] = acc[1];
                         }
-                        if (need_cm) acc_cm[j][i] = fmaf(gi * rmrd, w[j][i], acc_cm[j][i]);
-                        if (need_sh) acc_sh[j][i] = fmaf(gws, w[j][i], acc_sh[j][i]);
+                        if (need_sh) {
+                            const f32x2 acc = __builtin_elementwise_fma(gws2, wv, f32x2{acc_sh[j][i], acc_sh[j][i + 1]});
+                            acc_sh[j][i] = acc[0];
+                            acc_sh[j][i + 1] = acc[1];
+                        }
                     }
                 }
+                gs[j] += gs2[0] + gs2[1];
+                acc_rm += arm2[0] + arm2[1];
             };
             // wave-uniform choice: every lane's segment is regular (the normal case) -> plain rint in the hot loop
             if (__builtin_amdgcn_ballot_w64(!regular) == 0) element_pass(std::true_type{});
