@@ -576,6 +576,9 @@ def mask_is_causal(attention_mask):
         return False
     if os.environ.get("OQ_NO_CAUSAL_FASTPATH"):      # A/B switch: always take the dense masked path
         return False
+    Tm = attention_mask.shape[-1]
+    if Tm >= 256 and Tm % 256 != 0:                  # the causal GEMM modes contract in 256-blocks: dense path instead
+        return False
     root = attention_mask._base if attention_mask._base is not None else attention_mask
     tag = (root._version, tuple(attention_mask.shape))
     cached = getattr(root, "_oq_causal", None)

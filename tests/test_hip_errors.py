@@ -1,0 +1,82 @@
+"""Error behaviour of the drop-in boundary on a GPU box: the C ABI returns an error code (surfaced as OQError) for
+shapes / alignments it does not support instead of launching, the Python surface keeps the reference's exceptions
+(quantize/quantizer.py:42,69,117), and unsupported attention problems fall back to the unfused HIP kernels -- never
+to a CPU or eager-PyTorch path."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_quantizer_argument_errors():
+    from omniquant_amd import ops, OQError
+    from omniquant_amd.quantizer import UniformAffineQuantizer
+    x = torch.randn(16, 256, device=DEV)
+    with pytest.raises(OQError):
+        ops.fake_quant(x[:, :252].contiguous(), 4)                 # cols not a multiple of 8
+    with pytest.raises(OQError):
+        ops.fake_quant(x, 4, seg=96)                                # cols % seg != 0
+    with pytest.raises(OQError):
+        ops.fake_quant(torch.empty(0, 256, device=DEV), 4)          # empty input
+    with pytest.raises(OQError):
+        ops.fake_quant(torch.randn(4, 8 * 512 * 8 + 8, device=DEV), 4)   # row longer than the kernel's maximum
+    with pytest.raises(AssertionError):
+        UniformAffineQuantizer(n_bits=1)                            # reference: assert 2 <= n_bits <= 16
+    q16 = UniformAffineQuantizer(n_bits=16, dynamic_method="per_token")
+    assert q16(x) is x                                              # 16 bit = pass-through (quantizer.py:109-110)
+    qc = UniformAffineQuantizer(n_bits=4, dynamic_method="per_cluster")
+    with pytest.raises(NotImplementedError):
+        qc(x)                                                       # quantizer.py:117
+    qg = UniformAffineQuantizer(n_bits=4, symmetric=True, dynamic_method="per_channel", group_size=96, shape=(16, 256), lwc=True)
+    with pytest.raises(NotImplementedError):
+        qg(x)                                                       # ragged groups: documented gap, loud
+    # the largest supported row and a 1-row tensor both work
+    big = torch.randn(2, 8 * 512 * 8, device=DEV)
+    y = ops.fake_quant(big, 4)
+    assert y.shape == big.shape and bool(torch.isfinite(y).all())
+    y1 = ops.fake_quant(torch.randn(1, 64, device=DEV), 3)
+    assert y1.shape == (1, 64)
+
+
+def test_gemm_and_attention_argument_errors():
+    from omniquant_amd import ops, OQError
+    a = torch.randn(64, 64, device=DEV).to(torch.bfloat16)
+    c = torch.empty(64, 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(OQError):
+        ops.gemm(a, a, c, 64, 64, 0, 64, 64, 64, True, True)        # empty contraction
+    with pytest.raises(OQError):
+        ops.gemm(a, a, c, 64, 64, 60, 60, 60, 64, True, True)       # K not a multiple of 8 for bf16 vector loads
+    with pytest.raises(OQError):
+        ops.gemm(a, a, c, 64, 64, 64, 64, 64, 64, True, True, tri=7)
+    # fused attention: only bf16 / head_dim 128 / T = 128 or a multiple of 256; everything else uses the unfused HIP path
+    q = torch.randn(1, 384, 2, 128, device=DEV).to(torch.bfloat16)
+    assert not ops.fused_attention_supported(q, True)               # T = 384
+    assert not ops.fused_attention_supported(q[:, :256], False)     # not causal
+    assert not ops.fused_attention_supported(q[:, :256].float(), True)
+    assert not ops.fused_attention_supported(torch.randn(1, 256, 2, 64, device=DEV).to(torch.bfloat16), True)
+    assert ops.fused_attention_supported(q[:, :256].contiguous(), True)
+    with pytest.raises(OQError):
+        ops.FusedCausalAttnFn.apply(q, q, q, 1.0 / math.sqrt(128))  # calling the fused kernel on an unsupported T is loud
+    # T = 384 is not a multiple of the causal GEMM's 256-block: the causal fast path is declined and the dense masked
+    # HIP kernels handle the problem
+    mask = torch.triu(torch.full((384, 384), torch.finfo(torch.float32).min, device=DEV), 1)
+    causal = ops.mask_is_causal(mask)
+    assert causal is False
+    p = ops.SoftmaxFn.apply(ops.AttnScoresFn.apply(q, q, causal), mask, 1.0 / math.sqrt(128), causal)
+    o = ops.AttnPVFn.apply(p, q, causal)
+    assert o.shape == q.shape and bool(torch.isfinite(o.float()).all())
+    assert ops.mask_is_causal(torch.triu(torch.full((512, 512), torch.finfo(torch.float32).min, device=DEV), 1))
+
+
+def test_cpu_tensors_are_refused_everywhere():
+    from omniquant_amd import ops, OQError
+    from omniquant_amd.actstats import ActStatCollector
+    x = torch.randn(8, 64)
+    for fn in (lambda: ops.fake_quant(x, 4), lambda: ops.LinearFn.apply(x, torch.randn(16, 64), None),
+               lambda: ops.NormFn.apply(x, torch.ones(64), None, 1e-6, False) if hasattr(ops, "NormFn") else (_ for _ in ()).throw(OQError("x")),
+               lambda: ActStatCollector().update("a", x)):
+        with pytest.raises((OQError, RuntimeError)):
+            fn()
