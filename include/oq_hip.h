@@ -148,7 +148,10 @@ int oq_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
 int oq_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* go, const float* lse,
                 float* dsum, void* ds_t, void* gk, void* gv, int dtype, int64_t bs, int64_t T, int nh, int nkv, int hd,
                 float scale, int causal, void* stream);
-/* loss[0] += mean((out-t1)^2) (+ mean((out-t2)^2) if t2); g = dloss/dout * gscale.  loss zeroed by caller. */
+/* loss[0] = mean((out-t1)^2) (+ mean((out-t2)^2) if t2); g = dloss/dout * gscale.  `loss` is a buffer of
+ * 1 + OQ_MSE_MAX_BLOCKS floats: loss[0] receives the result, loss[1..] is scratch for the per-workgroup partial sums
+ * that a second tiny kernel adds in a fixed order (no atomics: the reported loss is bit-reproducible). */
+#define OQ_MSE_MAX_BLOCKS 1024
 int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, int dtype, int64_t n, float gscale,
                    float* loss, void* g, void* stream);
 /* y = a + b (residual) and y = a * s (OPT query scaling) */

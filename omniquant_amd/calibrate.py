@@ -106,7 +106,8 @@ class StepRunner:
         self.x = torch.zeros(sample_shape, dtype=dtype, device=dev)
         self.t1 = torch.zeros(sample_shape, dtype=dtype, device=dev)
         self.t2 = torch.zeros(sample_shape, dtype=dtype, device=dev) if aug_loss else None
-        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._loss_buf = torch.zeros(1 + 1024, dtype=torch.float32, device=dev)     # [0] loss, [1:] oq_mse scratch
+        self.loss = self._loss_buf[:1]
         self.graph = None
         self.use_graph = use_graph
         self.steps = 0
@@ -123,10 +124,9 @@ class StepRunner:
     def _step(self):
         self.qlayer.smooth_and_quant_temporary()
         out = self._forward()
-        self.loss.zero_()
         g = torch.empty_like(out)
         C.call("oq_mse_fwd_bwd", C.ptr(out), C.ptr(self.t1), C.ptr(self.t2), C.dt(out), out.numel(), 1.0,
-               C.fptr(self.loss), C.ptr(g), C.stream())
+               C.fptr(self._loss_buf), C.ptr(g), C.stream())
         self.opt.zero_grad()
         out.backward(g)
         self.opt.step()

@@ -97,6 +97,11 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // ---------------------------------------------------------------------------------------------------
 // forward: workgroup = 128 queries of one head (4 waves x 32 queries), key/value tiles of 64 through LDS
 // ---------------------------------------------------------------------------------------------------
+// HAZARD NOTE: the accumulators of an MFMA must only be read by compiler-generated instructions.  The first version
+// took the row maximum with the inline-asm `vmax` helper: hipcc's hazard recogniser does not insert the wait states an
+// MFMA result needs before an INLINE-ASM VALU reads it, so the maximum was occasionally taken from a not-yet-written
+// register -- still a valid softmax shift (results differed by 1 bf16 ulp in whole rows), but not run-to-run
+// reproducible.  `tools/debug_attn_det.py` checks bitwise reproducibility; the tests do as well.
 // One key/value tile for one wave.  DIAG: the tile crosses the diagonal of this wave's queries (mask needed).
 // dq = (query index of lane's column) - (first key of the tile) - 4*(lane>>4): key 16kb+i is masked iff 16kb+i > dq.
 template <bool DIAG>
@@ -129,11 +134,11 @@ __device__ __forceinline__ void fwd_tile(const char* Ks, const char* Vs, const b
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (DIAG && 16 * kb + i > dq[qb]) st[kb][qb][i] = -INFINITY;
-                mx = vmax(mx, st[kb][qb][i]);
+                mx = fmaxf(mx, st[kb][qb][i]);     // NOT the inline-asm vmax: see the hazard note above fwd_tile
             }
-        mx = vmax(mx, xor16(mx));
-        mx = vmax(mx, xor32(mx));
-        mx = vmax(m[qb], mx * c2);               // running maximum in the scaled log2 domain
+        mx = fmaxf(mx, xor16(mx));
+        mx = fmaxf(mx, xor32(mx));
+        mx = fmaxf(m[qb], mx * c2);               // running maximum in the scaled log2 domain
         const float alpha = __builtin_amdgcn_exp2f(m[qb] - mx);
         m[qb] = mx;
         float ls = 0.f;

@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const T* p, const T* g
 // ---- MSE loss + gradient -------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) mse_kernel(const T* out, const T* t1, const T* t2, int64_t n, float gscale,
-                                                  float* loss, T* g) {
+                                                  float* part, T* g) {
     __shared__ float red[4];
     const int64_t nvec = n / 8;
     const float inv_n = 1.f / (float)n;
@@ -229,7 +229,14 @@ __global__ void __launch_bounds__(256) mse_kernel(const T* out, const T* t1, con
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (lane == 0) red[wid] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) * inv_n;     // no atomics: fixed-order sum below
+}
+
+__global__ void __launch_bounds__(64) mse_final_kernel(const float* part, int nblocks, float* loss) {
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) a += part[i];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) loss[0] = a;
 }
 
 template <typename TS, typename TD>
@@ -376,10 +383,18 @@ extern "C" int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, i
     EW_CHECK("oq_mse_fwd_bwd", n);
     OQ_CHECK_ARG(out && t1 && loss && g, "oq_mse_fwd_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t grid = ew_grid(n / 8) > 1024 ? 1024 : ew_grid(n / 8);
-    DT_SWITCH("oq_mse_fwd_bwd", dtype,
-              hipLaunchKernelGGL((mse_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)out, (const float*)t1, (const float*)t2, n, gscale, loss, (float*)g),
-              hipLaunchKernelGGL((mse_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)t1, (const bf16_t*)t2, n, gscale, loss, (bf16_t*)g));
+    const int64_t grid = ew_grid(n / 8) > OQ_MSE_MAX_BLOCKS ? OQ_MSE_MAX_BLOCKS : ew_grid(n / 8);
+    if (dtype == OQ_F32)
+        hipLaunchKernelGGL((mse_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)out, (const float*)t1, (const float*)t2, n, gscale, loss + 1, (float*)g);
+    else if (dtype == OQ_BF16)
+        hipLaunchKernelGGL((mse_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)t1, (const bf16_t*)t2, n, gscale, loss + 1, (bf16_t*)g);
+    else {
+        oq_set_error("oq_mse_fwd_bwd: dtype %d unsupported", dtype);
+        return OQ_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, loss + 1, (int)grid, loss);
+    OQ_CHECK_LAUNCH("oq_mse_fwd_bwd");
+    return OQ_OK;
 }
 
 extern "C" int oq_cast(const void* x, int src_dtype, void* y, int dst_dtype, int64_t n, void* stream) {
