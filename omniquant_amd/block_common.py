@@ -77,29 +77,50 @@ class QuantBlockMixin:
         else:
             mod._temp_ready = None
 
-    def _let_temporaries(self, out_dtype):
+    def _let_temporaries(self, out_dtype, lazy_mlp=False):
         """Fused LET path: 6 fused transform+fake-quant kernels (one per smoothed linear) + ONE vector kernel for
-        every norm weight/bias and projection bias.  Returns {module: (temp_weight, temp_bias)} and the norm temps."""
+        every norm weight/bias and projection bias.  Returns {module: (temp_weight, temp_bias)} and the norm temps.
+        lazy_mlp: the MLP weights (no coupling with the vector kernel) are NOT quantised here; instead
+        `lazy[mod]` is a closure that does it right before the module's GEMM, so that the 0.27 GB of MLP fake-quant
+        weights do not flush the attention projections' weights out of the 256 MB Infinity Cache before they are used
+        (same kernels, same values, different issue order)."""
         nm = self._let_names()
         from . import ops
         specs = L.block_let_specs(nm, self, None)
-        wq, ws = {}, {}
-        for mod, sp in specs.items():
-            if sp.shift is not None:
-                wq[mod], ws[mod] = mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype, col_mul=sp.col_mul,
-                                                                 row_div=sp.row_div, row_mul=sp.row_mul, shift=sp.shift)
-            else:
-                wq[mod] = mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype)
-        q, k, v, o, ln1, ln2 = nm["q"], nm["k"], nm["v"], nm["o"], nm["ln1"], nm["ln2"]
         f = self._f32c
+        mlp = set(nm["fc1"]) | {nm["last"]} if lazy_mlp else set()
+        wq, ws, lazy = {}, {}, {}
+
+        def quant(mod, sp):
+            if sp.shift is not None:
+                return mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype, col_mul=sp.col_mul,
+                                                     row_div=sp.row_div, row_mul=sp.row_mul, shift=sp.shift)
+            return mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype), None
+
+        def mlp_bias(mod, wsh):
+            if mod is nm["last"]:
+                return mod.bias
+            return wsh if mod.bias is None else f(mod.bias) + wsh
+
+        for mod, sp in specs.items():
+            if mod in mlp:
+                def make(mod=mod, sp=sp):
+                    w_, ws_ = quant(mod, sp)
+                    mod.temp_weight, mod.temp_bias = w_, mlp_bias(mod, ws_)
+                lazy[mod] = make
+            else:
+                wq[mod], ws[mod] = quant(mod, sp)
+        q, k, v, o, ln1, ln2 = nm["q"], nm["k"], nm["v"], nm["o"], nm["ln1"], nm["ln2"]
         ln1_tw, ln1_tb, ln2_tw, ln2_tb, b_q, b_k, b_v, b_o = ops.LetVectorsFn.apply(
             self.qkv_smooth_scale, self.qkv_smooth_shift, self.out_smooth_scale, self.out_smooth_shift,
             self.fc1_smooth_scale, self.fc1_smooth_shift, self.qkt_smooth_scale,
             ws[q], ws[k], ws[v], ws[o], f(ln1.weight), f(getattr(ln1, "bias", None)), f(ln2.weight),
             f(getattr(ln2, "bias", None)), f(q.bias), f(k.bias), f(v.bias), f(o.bias))
-        bias = {q: b_q, k: b_k, v: b_v, o: b_o, nm["last"]: nm["last"].bias}
-        for fc in nm["fc1"]:
-            bias[fc] = ws[fc] if fc.bias is None else f(fc.bias) + ws[fc]
+        bias = {q: b_q, k: b_k, v: b_v, o: b_o}
+        for mod in list(wq):
+            if mod not in bias:
+                bias[mod] = mlp_bias(mod, ws[mod])
+        self.__dict__["_lazy_let"] = lazy
         return wq, bias, (ln1_tw, ln1_tb), (ln2_tw, ln2_tb)
 
     def smooth_and_quant_temporary(self):
@@ -113,10 +134,16 @@ class QuantBlockMixin:
             self._truncate_scales()
             if forked:
                 side.wait_stream(main)      # parameters were updated (AdamW / truncate) on the main stream
+            lazy_mlp = bool(self.__dict__.get("_lazy_mlp_quant")) and not forked
             with torch.cuda.stream(side):
-                wq, bias, t1, t2 = self._let_temporaries(dt)
+                wq, bias, t1, t2 = self._let_temporaries(dt, lazy_mlp)
                 for mod in wq:
                     self._publish(mod, wq[mod], bias[mod], side, forked)
+                for mod, fn in self.__dict__.pop("_lazy_let", {}).items():
+                    mod.temp_weight, mod.temp_bias = None, None
+                    mod.use_temporary_parameter = True
+                    mod._temp_ready = None
+                    mod.__dict__["_lazy_temp"] = fn
             if forked:
                 main.wait_stream(side)      # norm weights/biases are needed at the very start of the block
                 # (the per-linear events above are then already satisfied; LWC-only blocks below overlap more)
@@ -126,13 +153,24 @@ class QuantBlockMixin:
         else:
             if forked:
                 side.wait_stream(main)
+            lazy_mlp = bool(self.__dict__.get("_lazy_mlp_quant")) and not forked
+            mlp = set(nm["fc1"]) | {nm["last"]} if lazy_mlp else set()
             with torch.cuda.stream(side):
                 for mod in self._quant_linears():
-                    self._publish(mod, mod.weight_quantizer.quantize(mod.weight, out_dtype=dt), mod.bias, side, forked)
+                    if mod in mlp:
+                        def make(mod=mod):
+                            mod.temp_weight, mod.temp_bias = mod.weight_quantizer.quantize(mod.weight, out_dtype=dt), mod.bias
+                        mod.temp_weight, mod.temp_bias = None, None
+                        mod.use_temporary_parameter = True
+                        mod._temp_ready = None
+                        mod.__dict__["_lazy_temp"] = make
+                    else:
+                        self._publish(mod, mod.weight_quantizer.quantize(mod.weight, out_dtype=dt), mod.bias, side, forked)
 
     def clear_temp_variable(self):
         nm = self._let_names()
         for mod in self._quant_linears() + [nm["ln1"], nm["ln2"]]:
+            mod.__dict__.pop("_lazy_temp", None)
             if hasattr(mod, "temp_weight"):
                 del mod.temp_weight
             if hasattr(mod, "temp_bias"):

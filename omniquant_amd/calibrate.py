@@ -113,6 +113,10 @@ class StepRunner:
         self.steps = 0
         # opt-in: on ROCm 7.2 a hipGraph replays its parallel branches on ONE hardware queue (measured: zero overlap in
         # the rocprofv3 trace), so the second stream only pays off for un-captured (eager) stepping
+        # MLP weights are fake-quantised right before their GEMMs instead of at the start of the step (cache locality;
+        # identical kernels and values).  OQ_LAZY_MLP=0 restores the reference's order for A/B.
+        if os.environ.get("OQ_LAZY_MLP", "1") != "0":
+            qlayer.__dict__["_lazy_mlp_quant"] = True
         if os.environ.get("OQ_WEIGHT_STREAM", "0") != "0":
             qlayer.__dict__["_fq_stream"] = torch.cuda.Stream(device=dev)   # see QuantBlockMixin._weight_stream
 

@@ -67,6 +67,9 @@ class QuantLinear(nn.Module):
         if sink is not None:                        # LET-init statistics ride on the FP teacher pass (actstats.py)
             sink[0].update(sink[1], input)
         if self.use_temporary_parameter:
+            lazy = self.__dict__.pop("_lazy_temp", None)
+            if lazy is not None:                    # deferred fake-quant of this weight (block_common._let_temporaries)
+                lazy()
             weight, bias = self.temp_weight, self.temp_bias
             ev = self.__dict__.get("_temp_ready")
             if ev is not None:                      # temp weight was produced on the block's weight stream
