@@ -281,12 +281,26 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const T* x, int64_t
     }
 }
 
+// out[c] = sum_k ws[k][c] in a fixed order: block = 64 columns x 4 slab groups; a thread adds the slabs k = sg, sg+4, ...
+// of its column with four independent accumulators (loads in flight), the groups are combined through LDS.
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* ws, int slabs, int64_t cols, float* out) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float a = 0.f;
-    for (int k = 0; k < slabs; ++k) a += ws[(int64_t)k * cols + c];
-    out[c] = a;
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        int k = sg;
+        for (; k + 12 < slabs; k += 16) {
+            a0 += ws[(int64_t)k * cols + c];
+            a1 += ws[(int64_t)(k + 4) * cols + c];
+            a2 += ws[(int64_t)(k + 8) * cols + c];
+            a3 += ws[(int64_t)(k + 12) * cols + c];
+        }
+        for (; k < slabs; k += 4) a0 += ws[(int64_t)k * cols + c];
+    }
+    red[sg][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sg == 0 && c < cols) out[c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 }  // namespace
@@ -416,7 +430,7 @@ extern "C" int oq_cast(const void* x, int src_dtype, void* y, int dst_dtype, int
 }
 
 static int colsum_slabs(int64_t rows) {
-    int64_t s = rows / 32;
+    int64_t s = rows / 64;
     return (int)(s < 1 ? 1 : (s > COLSUM_MAX_SLABS ? COLSUM_MAX_SLABS : s));
 }
 
@@ -439,7 +453,7 @@ extern "C" int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, f
         oq_set_error("oq_colsum: dtype %d unsupported", dtype);
         return OQ_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, st, workspace, slabs, cols, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(256), 0, st, workspace, slabs, cols, out);
     OQ_CHECK_LAUNCH("oq_colsum");
     return OQ_OK;
 }
