@@ -135,6 +135,13 @@ int64_t oq_act_stats_workspace(int64_t nsamp, int64_t cols);
 int oq_act_stats(const void* x, int dtype, int64_t nsamp, int64_t rows, int64_t cols, float* scale, float* shift,
                  int64_t seen, float* workspace, int64_t workspace_floats, void* stream);
 
+/* ---- real-quant packing (quantize/omniquant.py:255-278 -> AutoGPTQ qlinear_cuda.QuantLinear.pack; the library is not
+ *      vendored in the reference: parity unpinned, see csrc/oq_pack.hip).  w [out,in] is the folded fake-quant weight,
+ *      scales / zeros [out, in/group] f32 (weight_quantizer.scales / .zeros viewed [out,-1]).  Outputs (int32):
+ *      qweight [in/32*bits, out], qzeros [in/group, out/32*bits] (zeros - 1, AutoGPTQ convention). ----------------- */
+int oq_pack_weights(const void* w, int dtype, int64_t out, int64_t in, int64_t group, int bits, const float* scales,
+                    const float* zeros, int32_t* qweight, int32_t* qzeros, void* stream);
+
 /* ---- fused causal attention (models/int_llama_layer.py:143-163 and its autograd; bf16, head_dim 128, exact
  *      causal mask, T == 128 or T % 256 == 0 -- oq_attn_supported() says whether a problem qualifies; everything else keeps using
  *      oq_gemm + oq_softmax_*).  q, o, go [bs,T,nh,hd]; k, v [bs,T,nkv,hd] (q/k/v already fake-quantised by the caller,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "oq_adamw": [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp],
     "oq_truncate": [_vp, _i64, _f32, _vp],
     "oq_act_stats": [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
+    "oq_pack_weights": [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_sum_vectors": [_i32, _vp, _vp, _vp, _vp, _vp],
     "oq_cast": [_vp, _i32, _vp, _i32, _i64, _vp],
     "oq_let_vectors_fwd": [_i64] + [_vp] * 28,

@@ -137,6 +137,55 @@ def act_stats(samples):
     return scale, shift
 
 
+def autogptq_pack(W, scales, zeros, bits, group_size=None):
+    """numpy restatement of AutoGPTQ qlinear_cuda.QuantLinear.pack (v0.4.x) as called at quantize/omniquant.py:264-265.
+    PARITY UNPINNED: the library is not vendored in the reference.  W [out,in] fake-quant weight, scales/zeros
+    [out, groups].  Returns (qweight [in/32*bits, out] int32, qzeros [groups, out/32*bits] int32)."""
+    import numpy as np
+    out, inn = W.shape
+    group = group_size or inn
+    g_idx = np.arange(inn) // group
+    s = scales.reshape(out, -1).t().contiguous().float()          # [groups, out]
+    z = zeros.reshape(out, -1).t().contiguous().float()
+    sz = z * s
+    inw = torch.round((W.float().t() + sz[g_idx]) / s[g_idx]).to(torch.int32).numpy().astype(np.uint32)     # [in, out]
+
+    def pack_rows(iw):
+        q = np.zeros((iw.shape[0] // 32 * bits, iw.shape[1]), dtype=np.uint32)
+        i = row = 0
+        while row < q.shape[0]:
+            if bits in (2, 4, 8):
+                for j in range(i, i + 32 // bits):
+                    q[row] |= iw[j] << np.uint32(bits * (j - i))
+                i += 32 // bits
+                row += 1
+            else:
+                for j in range(i, i + 10):
+                    q[row] |= iw[j] << np.uint32(3 * (j - i))
+                i += 10
+                q[row] |= iw[i] << np.uint32(30)
+                row += 1
+                q[row] |= (iw[i] >> np.uint32(2)) & np.uint32(1)
+                i += 1
+                for j in range(i, i + 10):
+                    q[row] |= iw[j] << np.uint32(3 * (j - i) + 1)
+                i += 10
+                q[row] |= iw[i] << np.uint32(31)
+                row += 1
+                q[row] |= (iw[i] >> np.uint32(1)) & np.uint32(3)
+                i += 1
+                for j in range(i, i + 10):
+                    q[row] |= iw[j] << np.uint32(3 * (j - i) + 2)
+                i += 10
+                row += 1
+        return q
+
+    qweight = pack_rows(inw)
+    zi = (z - 1).numpy().astype(np.uint32)                     # [groups, out]
+    qzeros = pack_rows(np.ascontiguousarray(zi.T)).T           # pack along the output channels
+    return torch.from_numpy(qweight.astype(np.int32)), torch.from_numpy(np.ascontiguousarray(qzeros).astype(np.int32))
+
+
 class QuantSpec:
     def __init__(self, wbits=4, abits=16, group_size=None, lwc=True, let=False, symmetric=False):
         self.wbits, self.abits, self.group_size = wbits, abits, group_size
