@@ -288,6 +288,9 @@ def calibrate_layers(layers, config, args, inps, attention_mask, position_ids=No
             omni_parameters[gi] = res["omni"]
             if getattr(args, "output_dir", None):
                 torch.save(omni_parameters, os.path.join(args.output_dir, "omni_parameters.pth"))
+        if getattr(args, "real_quant", False):
+            from .realquant import pack_block
+            pack_block(qlayer, args.wbits)         # quantize/omniquant.py:255-278
         qlayers.append(qlayer if keep_on_device else qlayer.to("cpu"))
     return qlayers, omni_parameters, all_losses, (quant_inps, fp_inps)
 

@@ -232,3 +232,23 @@ def test_calibration_is_bitwise_reproducible():
     assert outs[0]["losses"] == outs[1]["losses"]
     for k_ in outs[0]["omni"]:
         assert torch.equal(outs[0]["omni"][k_], outs[1]["omni"][k_]), k_
+
+
+def test_real_quant_after_calibration():
+    """--real_quant: after calibrate_layers every QuantLinear of the block is a PackedLinear whose dequantised weight
+    equals the folded fake-quant weight (fp16 scales), for a grouped W4A16 LLaMA block."""
+    from omniquant_amd.calibrate import calibrate_layers, default_args
+    from omniquant_amd.synthetic import make_config, make_layer, make_calib_inputs, causal_mask
+    from omniquant_amd.realquant import PackedLinear
+    cfg = make_config(None, family="llama", hidden_size=256, inter=512, heads=2, kv_heads=2)
+    args = default_args(wbits=4, abits=16, group_size=64, lwc=True, let=False, epochs=1, nsamples=2, net="llama", real_quant=True)
+    x = make_calib_inputs(2, 64, 256, dtype=torch.float16).to(DEV)
+    mask = causal_mask(64).to(DEV)
+    pos = torch.arange(64, device=DEV)[None]
+    qlayers, omni, losses, _ = calibrate_layers([make_layer(cfg, seed=2, device=DEV)], cfg, args, x, mask, pos, use_graph=False)
+    packed = [m for m in qlayers[0].modules() if isinstance(m, PackedLinear)]
+    assert len(packed) == 7
+    for m in packed:
+        w = m.dequantize()
+        assert w.shape == (m.outfeatures, m.infeatures) and bool(torch.isfinite(w.float()).all())
+        assert m.qweight.shape == (m.infeatures // 32 * 4, m.outfeatures) and m.qzeros.shape == (m.infeatures // 64, m.outfeatures // 32 * 4)
