@@ -1,7 +1,7 @@
 // OmniLlamaRMSNorm / OmniLayerNorm forward + backward for gfx950 (quantize/omni_norm.py:26-34,:52-63).
 // One workgroup per row (row kept in registers, <= 4 chunks of 8 per lane), f32 statistics.
-// Backward column sums (gw, gb) are accumulated in registers over the rows a workgroup walks and flushed with
-// one float atomic per column per workgroup.
+// Backward column sums (gw, gb) are accumulated in registers over the rows a workgroup walks, written as one partial
+// row per workgroup and finished by norm_colreduce_kernel in a fixed order (no atomics).
 #include "oq_common.h"
 
 namespace {

@@ -2,11 +2,12 @@
 // re-parameterisation.  Forward and closed-form backward.
 //
 // Replaces (reference, /root/reference): quantize/quantizer.py:15-19,84-105,122-147 and the weight side of
-// models/transformation.py:24-69.  HBM-bound: every matrix element is read ONCE (one workgroup owns a whole
-// row and keeps it in registers: <=4 chunks of 8 elements per lane), reduced with wave shuffles (+ LDS across
-// waves for whole-row segments), quantised and written once.  Column-wise LET gradients are accumulated in
-// registers across the rows a workgroup walks (lane -> column mapping is fixed) and flushed with one float
-// atomic per column per workgroup.
+// models/transformation.py:24-69.  Every matrix element is read ONCE (one workgroup owns a whole row and keeps it in
+// registers: 1-8 chunks of 8 elements per lane; the next row is prefetched as raw vectors), reduced with DPP wave
+// reductions (+ one LDS exchange across waves for whole-row segments), quantised and written once.  Column-wise LET
+// gradients are accumulated in registers across the rows a workgroup walks (lane -> column mapping is fixed), written
+// as per-workgroup partial rows and finished by colreduce_kernel in a fixed order (no atomics anywhere).
+// By bytes these kernels are HBM-bound; measured, they are bound by VALU issue.
 #include <stdlib.h>
 #include <type_traits>
 #include "oq_common.h"
