@@ -33,13 +33,17 @@ def pipeline_teacher_boundaries(inps, lo, hi, teacher_chunk_forward, group=None)
     """Step 2.  `teacher_chunk_forward(lo, hi, bank) -> bank` runs layers [lo, hi) with quantisation off.
     Returns the FP activation bank at THIS rank's chunk input (rank 0: `inps` itself)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # RCCL ("nccl") moves device buffers directly over xGMI; gloo (CPU tests, or ranks sharing one GPU) has no
+    # device point-to-point, so the bank is staged through host memory there
+    staged = inps.is_cuda and dist.get_backend(group) == "gloo"
     bank = inps
     if rank > 0:
-        bank = torch.empty_like(inps)
-        dist.recv(bank, src=rank - 1, group=group)
+        buf = torch.empty(inps.shape, dtype=inps.dtype, device="cpu" if staged else inps.device)
+        dist.recv(buf, src=rank - 1, group=group)
+        bank = buf.to(inps.device) if staged else buf
     if rank < world - 1:
-        out = teacher_chunk_forward(lo, hi, bank.clone())
-        dist.send(out.contiguous(), dst=rank + 1, group=group)
+        out = teacher_chunk_forward(lo, hi, bank.clone()).contiguous()
+        dist.send(out.cpu() if staged else out, dst=rank + 1, group=group)
     return bank
 
 
