@@ -78,11 +78,13 @@ int64_t oq_fakequant_bwd_workspace(int64_t rows, int64_t cols);
  *   2 contraction restricted to k < m0 + tile_m (P@V, dS@K);  3 contraction restricted to k >= m0 (dS^T@Q, P^T@dO).
  *   Modes 2/3 rely on the masked part of the [T,T] operand being ZERO inside the diagonal 256-block (what
  *   oq_softmax_fwd/bwd write with causal=1); everything beyond that block is never read.
+ * addend (optional, out_dtype, same leading dimension and batch strides as c, may alias c): c = alpha*A.B + bias + addend
+ *   -- the residual add of the block (models/int_llama_layer.py:246,264) or a gradient accumulation fused into the store.
  * in_dtype OQ_BF16: bf16 operands on v_mfma_f32_16x16x32_bf16, f32 accumulate.
  * in_dtype OQ_F32 : exact f32 on v_mfma_f32_16x16x4_f32 (parity mode).
  * out_dtype OQ_F32 or OQ_BF16.  Alignment: contiguous dims and leading dims multiples of 8 elements.
  */
-int oq_gemm(const void* a, const void* bm, void* c, const float* bias,
+int oq_gemm(const void* a, const void* bm, void* c, const float* bias, const void* addend,
             int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
             int a_kc, int b_kc, int in_dtype, int out_dtype, float alpha,
             int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,

@@ -22,7 +22,7 @@ SIGNATURES = {
                          _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
     "oq_fakequant_bwd": [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
-    "oq_gemm": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
+    "oq_gemm": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp],
     "oq_norm_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],

@@ -33,6 +33,7 @@ struct GemmP {
     const void* b;
     void* c;
     const float* bias;
+    const void* addend;      // optional: same dtype / leading dim / batch strides as C; C = alpha*A.B + bias + addend
     int64_t M, N, K, lda, ldb, ldc;
     int a_kc, b_kc;
     float alpha;
@@ -232,6 +233,19 @@ __global__ void __launch_bounds__(256, 2) gemm_bf16_kernel(GemmP p) {
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[i][j][r] * p.alpha;
                 if (p.bias) v[r] += p.bias[n + r];
+            }
+            if (p.addend) {          // residual / gradient accumulation fused into the store (may alias C)
+                const TOUT* ad = reinterpret_cast<const TOUT*>(p.addend) + (C - reinterpret_cast<TOUT*>(p.c)) + m * p.ldc + n;
+                if constexpr (sizeof(TOUT) == 4) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(ad);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += av[r];
+                } else {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf4a;
+                    const bf4a av = *reinterpret_cast<const bf4a*>(ad);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)av[r];
+                }
             }
             TOUT* dst = C + m * p.ldc + n;
             if constexpr (sizeof(TOUT) == 4) {
@@ -536,6 +550,19 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
                 v[r] = acc[i][j][r] * p.alpha;
                 if (p.bias) v[r] += p.bias[n + r];
             }
+            if (p.addend) {          // residual / gradient accumulation fused into the store (may alias C)
+                const TOUT* ad = reinterpret_cast<const TOUT*>(p.addend) + (C - reinterpret_cast<TOUT*>(p.c)) + m * p.ldc + n;
+                if constexpr (sizeof(TOUT) == 4) {
+                    const f32x4 av = *reinterpret_cast<const f32x4*>(ad);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += av[r];
+                } else {
+                    typedef __attribute__((ext_vector_type(4))) __bf16 bf4a;
+                    const bf4a av = *reinterpret_cast<const bf4a*>(ad);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)av[r];
+                }
+            }
             TOUT* dst = C + m * p.ldc + n;
             if constexpr (sizeof(TOUT) == 4) {
                 *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
@@ -749,6 +776,19 @@ __global__ void __launch_bounds__(512) gemm_bf16_pp_kernel(GemmP p, int total, i
                             v[r] = acc[i][j][r] * p.alpha;
                             if (p.bias) v[r] += p.bias[n + r];
                         }
+                        if (p.addend) {
+                            const TOUT* ad = reinterpret_cast<const TOUT*>(p.addend) + (C - reinterpret_cast<TOUT*>(p.c)) + m * p.ldc + n;
+                            if constexpr (sizeof(TOUT) == 4) {
+                                const f32x4 av = *reinterpret_cast<const f32x4*>(ad);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += av[r];
+                            } else {
+                                typedef __attribute__((ext_vector_type(4))) __bf16 bf4a;
+                                const bf4a av = *reinterpret_cast<const bf4a*>(ad);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += (float)av[r];
+                            }
+                        }
                         TOUT* dst = C + m * p.ldc + n;
                         if constexpr (sizeof(TOUT) == 4) {
                             *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
@@ -849,6 +889,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
                 if (m < p.M && n < p.N) {
                     float v = acc[i][j][r] * p.alpha;
                     if (p.bias) v += p.bias[n];
+                    if (p.addend) v += (float)(reinterpret_cast<const TOUT*>(p.addend) + (C - reinterpret_cast<TOUT*>(p.c)))[m * p.ldc + n];
                     C[m * p.ldc + n] = (TOUT)v;
                 }
             }
@@ -856,7 +897,8 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
 
 }  // namespace
 
-extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias, int64_t M, int64_t N, int64_t K,
+extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias, const void* addend, int64_t M, int64_t N,
+                       int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
                        float alpha, int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o,
                        int64_t sb_i, int64_t sc_o, int64_t sc_i, int tri_mode, void* stream) {
@@ -866,7 +908,7 @@ extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias
     OQ_CHECK_ARG(batch_o * batch_i <= 65535, "oq_gemm: batch %lld too large", (long long)(batch_o * batch_i));
     OQ_CHECK_ARG(out_dtype == OQ_F32 || out_dtype == OQ_BF16, "oq_gemm: out dtype %d", out_dtype);
     GemmP p{};
-    p.a = a; p.b = bm; p.c = c; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.a = a; p.b = bm; p.c = c; p.bias = bias; p.addend = addend; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.a_kc = a_kc; p.b_kc = b_kc; p.alpha = alpha; p.batch_i = batch_i;
     p.sa_o = sa_o; p.sa_i = sa_i; p.sb_o = sb_o; p.sb_i = sb_i; p.sc_o = sc_o; p.sc_i = sc_i;
     OQ_CHECK_ARG(tri_mode >= 0 && tri_mode <= 3, "oq_gemm: tri_mode %d", tri_mode);

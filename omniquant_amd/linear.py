@@ -1,4 +1,6 @@
 """QuantLinear on the HIP path.  Surface = reference quantize/int_linear.py:11-69."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -6,10 +8,10 @@ from . import ops
 from .quantizer import UniformAffineQuantizer
 
 
-def _hip_linear(input, weight, bias=None):
+def _hip_linear(input, weight, bias=None, residual=None):
     if weight.dtype != input.dtype:
         weight = ops.cast(weight, input.dtype)
-    return ops.LinearFn.apply(input, weight, bias)
+    return ops.LinearFn.apply(input, weight, bias, residual)
 
 
 class QuantLinear(nn.Module):
@@ -62,10 +64,9 @@ class QuantLinear(nn.Module):
             return self.act_quantizer(input)
         return input
 
-    def forward(self, input: torch.Tensor, input_is_quantized: bool = False):
-        sink = self.__dict__.get("_stat_sink")
-        if sink is not None:                        # LET-init statistics ride on the FP teacher pass (actstats.py)
-            sink[0].update(sink[1], input)
+    def _resolve(self, dtype):
+        """(weight, bias) this forward uses: the step's temporaries (produced lazily if deferred), the on-the-fly
+        fake-quant weight, or the raw / folded weight cast to the activation dtype."""
         if self.use_temporary_parameter:
             lazy = self.__dict__.pop("_lazy_temp", None)
             if lazy is not None:                    # deferred fake-quant of this weight (block_common._let_temporaries)
@@ -78,13 +79,43 @@ class QuantLinear(nn.Module):
                 weight.record_stream(cur)
                 if bias is not None:
                     bias.record_stream(cur)
-        elif self.use_weight_quant:
-            weight, bias = self.weight_quantizer.quantize(self.weight, out_dtype=input.dtype), self.bias
-        else:
-            weight, bias = self._weight_as(input.dtype), self.bias
+            return weight, bias
+        if self.use_weight_quant:
+            return self.weight_quantizer.quantize(self.weight, out_dtype=dtype), self.bias
+        return self._weight_as(dtype), self.bias
+
+    def forward(self, input: torch.Tensor, input_is_quantized: bool = False, residual=None):
+        """residual (HIP-path extension): added to the output inside the GEMM's store (the block's residual add)."""
+        sink = self.__dict__.get("_stat_sink")
+        if sink is not None:                        # LET-init statistics ride on the FP teacher pass (actstats.py)
+            sink[0].update(sink[1], input)
+        weight, bias = self._resolve(input.dtype)
         if not input_is_quantized:
             input = self.quantize_input(input)
+        if residual is not None:
+            return self.fwd_func(input, weight, bias, residual=residual, **self.fwd_kwargs)
         return self.fwd_func(input, weight, bias, **self.fwd_kwargs)
+
+    @staticmethod
+    def forward_siblings(mods, input):
+        """Projections reading the SAME (already act-quantised) input: one autograd node whose backward accumulates
+        the input gradient in the dgrad GEMMs' epilogue (ops.SiblingLinearFn).  Falls back to independent calls when a
+        module does not use the HIP GEMM as its fwd_func."""
+        # opt-in (OQ_SIBLING=1): measured 1 % SLOWER than independent projections + autograd's add launches on the 7B
+        # step (same-box A/B 245.9 vs 248.6 sample-steps/s): the epilogue's read-modify-write of the 16.8 MB gradient
+        # costs more inside the MFMA kernel than in a streaming add
+        if os.environ.get("OQ_SIBLING", "0") == "0" or any(m.fwd_func is not _hip_linear or m.fwd_kwargs for m in mods):
+            return tuple(m(input, True) for m in mods)
+        wb = []
+        for m in mods:
+            sink = m.__dict__.get("_stat_sink")
+            if sink is not None:
+                sink[0].update(sink[1], input)
+            w, b = m._resolve(input.dtype)
+            if w.dtype != input.dtype:
+                w = ops.cast(w, input.dtype)
+            wb += [w, b]
+        return ops.SiblingLinearFn.apply(input, *wb)
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self.use_weight_quant = weight_quant

@@ -33,9 +33,10 @@ class QuantLlamaMLP(nn.Module):
         if hidden_act not in ("silu", "swish"):
             raise NotImplementedError(f"hidden_act {hidden_act}: only SiLU has a HIP kernel")
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         xq = self.gate_proj.quantize_input(x)       # gate/up share one act-quant pass (identical settings)
-        return self.down_proj(ops.SiluMulFn.apply(self.gate_proj(xq, True), self.up_proj(xq, True)))
+        gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq)
+        return self.down_proj(ops.SiluMulFn.apply(gate, up), residual=residual)   # residual add fused into the GEMM store
 
 
 class QuantLlamaAttention(nn.Module):
@@ -78,15 +79,14 @@ class QuantLlamaAttention(nn.Module):
         return cos, sin
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
-                output_attentions=False, use_cache=False):
+                output_attentions=False, use_cache=False, residual=None):
         if past_key_value is not None or use_cache or output_attentions:
             raise NotImplementedError("the calibration hot path runs without KV cache / attention outputs")
         bsz, q_len, _ = hidden_states.size()
         nh, nkv, hd = self.num_heads, self.num_key_value_heads, self.head_dim
         hq = self.q_proj.quantize_input(hidden_states)      # q/k/v share one act-quant pass
-        q = self.q_proj(hq, True).view(bsz, q_len, nh, hd)
-        k = self.k_proj(hq, True).view(bsz, q_len, nkv, hd)
-        v = self.v_proj(hq, True).view(bsz, q_len, nkv, hd)
+        q, k, v = QuantLinear.forward_siblings([self.q_proj, self.k_proj, self.v_proj], hq)
+        q, k, v = q.view(bsz, q_len, nh, hd), k.view(bsz, q_len, nkv, hd), v.view(bsz, q_len, nkv, hd)
         cos, sin = self._rope_tables(position_ids, q_len, hidden_states.device)
         q = ops.RopeFn.apply(q, cos, sin)
         k = ops.RopeFn.apply(k, cos, sin)
@@ -113,7 +113,7 @@ class QuantLlamaAttention(nn.Module):
             probs = self.pv_matmul.quant_x1(probs)
             v = self.pv_matmul.quant_x2(v)
             attn = self.pv_matmul.apply_probs(probs, v, causal)        # [bs, T, nh, hd]
-        attn = self.o_proj(attn.view(bsz, q_len, self.hidden_size))
+        attn = self.o_proj(attn.view(bsz, q_len, self.hidden_size), residual=residual)   # (+ residual in the GEMM store)
         return attn, None, None
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
@@ -144,11 +144,10 @@ class QuantLlamaDecoderLayer(QuantBlockMixin, nn.Module):
                 output_attentions=False, use_cache=False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         residual = hidden_states
         h = self.input_layernorm(hidden_states)
-        h, _, _ = self.self_attn(hidden_states=h, attention_mask=attention_mask, position_ids=position_ids,
-                                 past_key_value=past_key_value, output_attentions=output_attentions, use_cache=use_cache)
-        hidden_states = ops.AddFn.apply(residual, h)
-        residual = hidden_states
+        # the two residual adds (models/int_llama_layer.py:246,264) are folded into the o_proj / down_proj GEMM stores
+        hidden_states, _, _ = self.self_attn(hidden_states=h, attention_mask=attention_mask, position_ids=position_ids,
+                                             past_key_value=past_key_value, output_attentions=output_attentions,
+                                             use_cache=use_cache, residual=residual)
         h = self.post_attention_layernorm(hidden_states)
-        h = self.mlp(h)
-        hidden_states = ops.AddFn.apply(residual, h)
+        hidden_states = self.mlp(h, residual=hidden_states)
         return (hidden_states,)

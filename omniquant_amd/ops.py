@@ -143,8 +143,11 @@ def fake_quant(x, nbits, seg=None, up=None, low=None, symmetric=False, out_dtype
 # GEMM
 # ------------------------------------------------------------------------------------------------------
 def gemm(a, b, c, M, N, K, lda, ldb, ldc, a_kc, b_kc, bias=None, alpha=1.0, batch_o=1, batch_i=1,
-         sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, tri=0):
-    """Raw strided-batched GEMM on device buffers (element offsets/strides)."""
+         sa=(0, 0), sb=(0, 0), sc=(0, 0), a_off=0, b_off=0, c_off=0, tri=0, addend=None):
+    """Raw strided-batched GEMM on device buffers (element offsets/strides).  addend: tensor with c's dtype / layout
+    that is added in the epilogue (may be c itself: accumulate)."""
+    if addend is not None and (addend.dtype != c.dtype or not addend.is_cuda or not addend.is_contiguous()):
+        raise C.OQError("gemm: addend must be a contiguous GPU tensor of the output dtype")
     for t in (a, b, c):
         if not t.is_cuda:
             raise C.OQError("gemm: the HIP path needs GPU tensors; there is no CPU fallback")
@@ -152,15 +155,16 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, a_kc, b_kc, bias=None, alpha=1.0, batc
             raise C.OQError("gemm: non-contiguous buffer")
     es_in, es_out = a.element_size(), c.element_size()
     C.call("oq_gemm", a.data_ptr() + a_off * es_in, b.data_ptr() + b_off * es_in, c.data_ptr() + c_off * es_out,
-           C.fptr(bias), M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc), C.dt(a), C.dt(c), float(alpha),
+           C.fptr(bias), None if addend is None else addend.data_ptr() + c_off * es_out, M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc), C.dt(a), C.dt(c), float(alpha),
            batch_o, batch_i, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], int(tri), C.stream())
 
 
 class LinearFn(torch.autograd.Function):
-    """y = x @ wq.T + bias  (quantize/int_linear.py:62) with dgrad / wgrad / bias-grad kernels."""
+    """y = x @ wq.T + bias (+ residual)  (quantize/int_linear.py:62; the residual add of
+    models/int_llama_layer.py:246,264 is folded into the GEMM's store) with dgrad / wgrad / bias-grad kernels."""
 
     @staticmethod
-    def forward(ctx, x, wq, bias):
+    def forward(ctx, x, wq, bias, residual=None):
         x2 = x.contiguous().view(-1, x.shape[-1])
         wq = wq.contiguous()
         T, K = x2.shape
@@ -169,9 +173,15 @@ class LinearFn(torch.autograd.Function):
             raise C.OQError(f"LinearFn: weight dtype {wq.dtype} != activation dtype {x2.dtype}")
         y = torch.empty((T, N), dtype=x2.dtype, device=x2.device)
         b32 = _f32(bias)
-        gemm(x2, wq, y, T, N, K, K, K, N, True, True, bias=b32)
+        res2 = None
+        if residual is not None:
+            if residual.dtype != x2.dtype or residual.numel() != T * N:
+                raise C.OQError("LinearFn: residual must have the output's dtype and size")
+            res2 = residual.contiguous().view(T, N)
+        gemm(x2, wq, y, T, N, K, K, K, N, True, True, bias=b32, addend=res2)
         ctx.save_for_backward(x2, wq)
         ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
         ctx.xshape = x.shape
         return y.view(*x.shape[:-1], N)
 
@@ -196,7 +206,64 @@ class LinearFn(torch.autograd.Function):
             ws_n = C.size_call("oq_colsum_workspace", T, N)
             ws = torch.empty(ws_n, dtype=torch.float32, device=gy2.device)
             C.call("oq_colsum", C.ptr(gy2), C.dt(gy2), T, N, C.fptr(gb), C.fptr(ws), ws_n, C.stream())
-        return gx, gw, gb
+        gres = gy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return gx, gw, gb, gres
+
+
+class SiblingLinearFn(torch.autograd.Function):
+    """Projections that read the SAME input (q/k/v; gate/up): y_i = x @ w_i.T + b_i.  One autograd node, so the
+    input gradient dX = sum_i dY_i @ W_i is ACCUMULATED by the dgrad GEMMs' epilogue (addend = the running sum) instead
+    of materialising every term and adding them with separate launches.  Inputs: x, then (w_i, b_i) pairs."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        T, K = x2.shape
+        ws = [w.contiguous() for w in wb[0::2]]
+        bs = list(wb[1::2])
+        outs = []
+        for w, b in zip(ws, bs):
+            if w.dtype != x2.dtype:
+                raise C.OQError(f"SiblingLinearFn: weight dtype {w.dtype} != activation dtype {x2.dtype}")
+            N = w.shape[0]
+            y = torch.empty((T, N), dtype=x2.dtype, device=x2.device)
+            gemm(x2, w, y, T, N, K, K, K, N, True, True, bias=_f32(b))
+            outs.append(y.view(*x.shape[:-1], N))
+        ctx.save_for_backward(x2, *ws)
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.xshape = x.shape
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        x2, *ws = ctx.saved_tensors
+        T, K = x2.shape
+        need = ctx.needs_input_grad
+        gx = None
+        grads = []
+        first = True
+        for i, (w, gy) in enumerate(zip(ws, gys)):
+            N = w.shape[0]
+            gw = gb = None
+            if gy is not None:
+                gy2 = gy.contiguous().view(T, N)
+                if need[0]:
+                    if gx is None:
+                        gx = torch.empty((T, K), dtype=x2.dtype, device=x2.device)
+                    gemm(gy2, w, gx, T, K, N, N, K, K, True, False, addend=None if first else gx)
+                    first = False
+                if need[1 + 2 * i]:
+                    gw = torch.empty((N, K), dtype=w.dtype, device=x2.device)
+                    gemm(gy2, x2, gw, N, K, T, N, K, K, False, False)
+                if ctx.has_bias[i] and need[2 + 2 * i]:
+                    gb = torch.empty((N,), dtype=torch.float32, device=x2.device)
+                    ws_n = C.size_call("oq_colsum_workspace", T, N)
+                    wsb = torch.empty(ws_n, dtype=torch.float32, device=gy2.device)
+                    C.call("oq_colsum", C.ptr(gy2), C.dt(gy2), T, N, C.fptr(gb), C.fptr(wsb), ws_n, C.stream())
+            grads += [gw, gb]
+        if gx is not None:
+            gx = gx.view(ctx.xshape)
+        return (gx, *grads)
 
 
 class AttnScoresFn(torch.autograd.Function):

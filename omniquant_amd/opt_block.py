@@ -38,16 +38,16 @@ class QuantOPTAttention(nn.Module):
         self.use_act_quant = False
 
     def forward(self, hidden_states, key_value_states=None, past_key_value=None, attention_mask=None,
-                layer_head_mask=None, output_attentions=False):
+                layer_head_mask=None, output_attentions=False, residual=None):
         if key_value_states is not None or past_key_value is not None or layer_head_mask is not None or output_attentions:
             raise NotImplementedError("the calibration hot path runs self-attention without cache / head masks")
         bsz, tgt_len, _ = hidden_states.size()
         nh, hd = self.num_heads, self.head_dim
         hq = self.q_proj.quantize_input(hidden_states)      # q/k/v share one act-quant pass
-        q = ops.ScaleFn.apply(self.q_proj(hq, True), self.scaling)
-        q = self.qkt_matmul.quant_x1(q)
-        k = self.qkt_matmul.quant_x2(self.k_proj(hq, True))
-        v = self.pv_matmul.quant_x2(self.v_proj(hq, True))
+        q, k, v = QuantLinear.forward_siblings([self.q_proj, self.k_proj, self.v_proj], hq)
+        q = self.qkt_matmul.quant_x1(ops.ScaleFn.apply(q, self.scaling))
+        k = self.qkt_matmul.quant_x2(k)
+        v = self.pv_matmul.quant_x2(v)
         q, k, v = (t.view(bsz, tgt_len, nh, hd) for t in (q, k, v))
         mask = None
         if attention_mask is not None:
@@ -60,7 +60,7 @@ class QuantOPTAttention(nn.Module):
         probs = ops.SoftmaxFn.apply(scores, mask, 1.0, causal)
         probs = self.pv_matmul.quant_x1(probs)
         attn = self.pv_matmul.apply_probs(probs, v, causal).view(bsz, tgt_len, self.embed_dim)
-        return self.out_proj(attn), None, None
+        return self.out_proj(attn, residual=residual), None, None      # (+ residual in the GEMM store)
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
         self.use_weight_quant = weight_quant
@@ -98,15 +98,14 @@ class QuantOPTDecoderLayer(QuantBlockMixin, nn.Module):
             raise NotImplementedError("the calibration hot path runs without KV cache / attention outputs")
         residual = hidden_states
         h = self.self_attn_layer_norm(hidden_states) if self.do_layer_norm_before else hidden_states
-        h, _, _ = self.self_attn(hidden_states=h, past_key_value=past_key_value, attention_mask=attention_mask,
-                                 layer_head_mask=layer_head_mask, output_attentions=output_attentions)
-        hidden_states = ops.AddFn.apply(residual, h)
+        hidden_states, _, _ = self.self_attn(hidden_states=h, past_key_value=past_key_value, attention_mask=attention_mask,
+                                             layer_head_mask=layer_head_mask, output_attentions=output_attentions,
+                                             residual=residual)      # residual add folded into out_proj's GEMM store
         if not self.do_layer_norm_before:
             hidden_states = self.self_attn_layer_norm(hidden_states)
         residual = hidden_states
         h = self.final_layer_norm(hidden_states) if self.do_layer_norm_before else hidden_states
-        h = self.fc2(ops.ReluFn.apply(self.fc1(h)))
-        hidden_states = ops.AddFn.apply(residual, h)
+        hidden_states = self.fc2(ops.ReluFn.apply(self.fc1(h)), residual=residual)
         if not self.do_layer_norm_before:
             hidden_states = self.final_layer_norm(hidden_states)
         return (hidden_states,)

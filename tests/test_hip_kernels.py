@@ -498,3 +498,40 @@ def test_real_quant_packing(bits, group):
     ng = inn // (group or inn)
     want = (wq.cpu().reshape(out, ng, -1) / sc.cpu().reshape(out, ng, 1)).round() * sc.cpu().reshape(out, ng, 1).half().float()
     assert float((back - want.reshape(out, inn)).abs().max()) <= 2e-3 * float(wq.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_addend_and_sibling_projections(dtype):
+    """oq_gemm's epilogue addend: (1) LinearFn(x, w, b, residual) == LinearFn(x, w, b) + residual (bit-exact in f32:
+    same operation order); (2) SiblingLinearFn (dgrad accumulated in the epilogue) vs three independent LinearFn."""
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(17)
+    T_, K, N = 256, 256, 384
+    x = torch.randn(T_, K, generator=g).to(dtype).to(DEV)
+    ws = [(torch.randn(N, K, generator=g) * 0.1).to(dtype).to(DEV) for _ in range(3)]
+    bs = [torch.randn(N, generator=g).to(DEV), None, torch.randn(N, generator=g).to(DEV)]
+    res = torch.randn(T_, N, generator=g).to(dtype).to(DEV)
+    y0 = ops.LinearFn.apply(x, ws[0], bs[0])
+    y1 = ops.LinearFn.apply(x, ws[0], bs[0], res)
+    if dtype == torch.float32:
+        assert torch.equal(y1, y0 + res)
+    else:
+        assert float((y1.float() - (y0.float() + res.float())).abs().max()) <= 2e-2 * float(y0.float().abs().max())
+    Gs = [torch.randn(T_, N, generator=g).to(dtype).to(DEV) for _ in range(3)]
+    xa = x.clone().requires_grad_(True)
+    wa = [w.clone().requires_grad_(True) for w in ws]
+    ya = [ops.LinearFn.apply(xa, w, b) for w, b in zip(wa, bs)]
+    sum((y.float() * G.float()).sum() for y, G in zip(ya, Gs)).backward()
+    xb = x.clone().requires_grad_(True)
+    wb = [w.clone().requires_grad_(True) for w in ws]
+    args = []
+    for w, b in zip(wb, bs):
+        args += [w, b]
+    yb = ops.SiblingLinearFn.apply(xb, *args)
+    sum((y.float() * G.float()).sum() for y, G in zip(yb, Gs)).backward()
+    for a, b in zip(ya, yb):
+        assert torch.equal(a, b)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert float((xa.grad.float() - xb.grad.float()).abs().max()) <= tol * float(xa.grad.float().abs().max())
+    for a, b in zip(wa, wb):
+        assert torch.equal(a.grad, b.grad)
