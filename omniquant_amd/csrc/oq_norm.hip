@@ -163,11 +163,16 @@ __global__ void __launch_bounds__(256) norm_colreduce_kernel(const float* part, 
     float a[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = 0.f;
-    if (c < cols) {
-        for (int b0 = rg * 8; b0 < nblocks; b0 += 128) {
+    if (c < cols) {          // 32 independent loads in flight per lane (see colreduce_kernel in oq_quant.hip)
+        for (int base = 0; base < nblocks; base += 512) {
+            float v[32];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (b0 + k < nblocks) a[k] += src[(int64_t)(b0 + k) * cols + c];
+            for (int k = 0; k < 32; ++k) {
+                const int b = base + rg + 16 * k;
+                v[k] = b < nblocks ? src[(int64_t)b * cols + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) a[k & 7] += v[k];
         }
     }
     red[rg][cl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));

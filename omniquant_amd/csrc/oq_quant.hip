@@ -671,14 +671,21 @@ __global__ void __launch_bounds__(256) colreduce_kernel(const float* part, int n
     const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int64_t c = (int64_t)blockIdx.x * 16 + cl;
     __shared__ float red[16][17];
+    // 32 independent loads in flight per lane (one memory round trip for up to 512 partial rows): the old loop of
+    // 4 dependent batches of 8 was latency-bound at ~11 us for 8 MB
     float a[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[k] = 0.f;
     if (c < cols) {
-        for (int b0 = rg * 8; b0 < nblocks; b0 += 128) {
+        for (int base = 0; base < nblocks; base += 512) {
+            float v[32];
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (b0 + k < nblocks) a[k] += src[(int64_t)(b0 + k) * cols + c];
+            for (int k = 0; k < 32; ++k) {
+                const int b = base + rg + 16 * k;
+                v[k] = b < nblocks ? src[(int64_t)b * cols + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) a[k & 7] += v[k];
         }
     }
     red[rg][cl] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
@@ -842,7 +849,7 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
     row_geometry(cols, 2, &ch, &bt);
     const bool full = (int64_t)ch * bt * 8 == cols;
     // column accumulators are flushed once per workgroup: keep the grid small when they are live
-    const int64_t cap = (g_col_mul || g_shift) ? OQ_FQ_BWD_MAX_BLOCKS : dbg_env("OQ_DBG_FQ_BLOCKS", OQ_FQ_MAX_BLOCKS);
+    const int64_t cap = (g_col_mul || g_shift) ? dbg_env("OQ_DBG_FQ_BWD_BLOCKS", OQ_FQ_BWD_MAX_BLOCKS) : dbg_env("OQ_DBG_FQ_BLOCKS", OQ_FQ_MAX_BLOCKS);
     const int64_t grid = rows < cap ? rows : cap;
     if (g_col_mul || g_shift) {
         OQ_CHECK_ARG(workspace && workspace_floats >= 2 * grid * cols,
@@ -869,6 +876,7 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
 }
 
 extern "C" int64_t oq_fakequant_bwd_workspace(int64_t rows, int64_t cols) {
-    const int64_t grid = rows < OQ_FQ_BWD_MAX_BLOCKS ? rows : OQ_FQ_BWD_MAX_BLOCKS;
+    const int64_t cap = dbg_env("OQ_DBG_FQ_BWD_BLOCKS", OQ_FQ_BWD_MAX_BLOCKS);
+    const int64_t grid = rows < cap ? rows : cap;
     return 2 * grid * cols;
 }
