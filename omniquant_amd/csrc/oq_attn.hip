@@ -14,8 +14,7 @@
 //
 // Layout: q, o, dO, dQ [bs, T, nh, 128]; k, v [bs, T, nkv, 128]; dK, dV [bs, T, nh, 128] (per q-head; the caller
 // reduces GQA groups).  LDS tiles are [64 rows][128 d] bf16 (256-B rows) with the 16-B chunk index XOR-swizzled by
-// s(row) = ((row&7)<<1)|((row>>3)&1): conflict-free for both ds_read_b128 row fragments (16 rows x one chunk) and
-// ds_read_b64_tr_b16 transposed fragments (8 rows x 32 B).
+// s(row) (see swz()): conflict-free for both ds_read_b128 row fragments and ds_read_b64_tr_b16 transposed fragments.
 //
 // MFMA operand trick (no cross-lane shuffles between the two GEMMs of a tile): the first product is computed so that
 // the softmax'd block comes out of the accumulator with the contraction index of the SECOND product along the
@@ -45,7 +44,17 @@ struct AttnP {
     float scale, scale_log2;
 };
 
-__device__ __forceinline__ int swz(int row) { return ((row & 7) << 1) | ((row >> 3) & 1); }
+// s(row): built for the DOCUMENTED lane groups of the two read instructions (MI355X_MICROARCH.md, LDS table):
+//   ds_read_b128 is served in 4 groups of 16 NON-contiguous lanes ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...): a group
+//   mixes rows {0-3,12-15} at chunk c with rows {4-11} at chunk c+1, so s must map {0-3,12-15} and {4-11} onto chunk
+//   sets that are each closed under XOR 1;  ds_read_b64_tr_b16 is served in two 32-lane halves = 8 consecutive rows x
+//   32 B, so s>>1 must be distinct over every aligned octet of rows.  (The first version used (row&7)<<1 | row>>3&1:
+//   fine for the transposed reads, 2-way conflicts on every ds_read_b128 -- SQ_LDS_BANK_CONFLICT = 24-27 % of
+//   SQ_LDS_IDX_ACTIVE.)
+__device__ __forceinline__ int swz(int row) {
+    const int hi = (row >> 3) & 1;
+    return ((((row & 7) ^ (hi << 2)) << 1) | hi);
+}
 
 __device__ __forceinline__ void tile_gload(const bf16_t* base, int64_t ld, int tid, u32x4 (&r)[4]) {
 #pragma unroll
