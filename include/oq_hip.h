@@ -105,6 +105,7 @@ int oq_norm_fwd(const void* x, int dtype, int64_t rows, int64_t cols, const floa
                 int is_layernorm, void* y, float* rstd, float* mean, void* stream);
 int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t rows, int64_t cols, const float* w,
                 const float* rstd, const float* mean, int is_layernorm, void* gx, float* gw, float* gb,
+                const void* gx_addend /* optional [rows,cols], x's dtype: gx += it (residual-path gradient) */,
                 float* workspace, int64_t workspace_floats, void* stream);
 int64_t oq_norm_bwd_workspace(int64_t rows, int64_t cols);
 

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(1024) norm_fwd_kernel(const T* x, int64_t rows
 template <typename T>
 __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, int64_t rows, int64_t cols,
                                                        const float* w, const float* rstd_in, const float* mean_in,
-                                                       int ln, T* gx, float* ws, int want_b) {
+                                                       int ln, T* gx, float* ws, int want_b, const T* gx_add) {
     __shared__ float red[16];
     const int t = threadIdx.x, BT = blockDim.x;
     float aw[MAXCH][8], ab[MAXCH][8];
@@ -137,6 +137,12 @@ __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, 
             float o[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = (gh[j][i] - s1 - xh[j][i] * s2) * rstd;
+            if (gx_add) {          // gradient that reached x on the residual path: added here instead of by a separate launch
+                float ga[8];
+                Vec8<T>::load(gx_add + r * cols + c0, ga);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] += ga[i];
+            }
             Vec8<T>::store(gx + r * cols + c0, o);
         }
     }
@@ -222,7 +228,7 @@ extern "C" int oq_norm_fwd(const void* x, int dtype, int64_t rows, int64_t cols,
 
 extern "C" int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t rows, int64_t cols, const float* w,
                            const float* rstd, const float* mean, int is_layernorm, void* gx, float* gw, float* gb,
-                           float* workspace, int64_t workspace_floats, void* stream) {
+                           const void* gx_addend, float* workspace, int64_t workspace_floats, void* stream) {
     OQ_CHECK_ARG(x && gy && gx && w && rstd, "oq_norm_bwd: null pointer");
     OQ_CHECK_ARG(oq_aligned16(w), "oq_norm_bwd: weight must be 16-byte aligned");
     OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 8 * 512 * MAXCH, "oq_norm_bwd: cols %lld", (long long)cols);
@@ -234,10 +240,10 @@ extern "C" int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t row
     hipStream_t st = (hipStream_t)stream;
     if (dtype == OQ_F32)
         hipLaunchKernelGGL((norm_bwd_kernel<float>), dim3(grid), dim3(bt), 0, st, (const float*)x, (const float*)gy, rows,
-                           cols, w, rstd, mean, is_layernorm, (float*)gx, workspace, gb ? 1 : 0);
+                           cols, w, rstd, mean, is_layernorm, (float*)gx, workspace, gb ? 1 : 0, (const float*)gx_addend);
     else if (dtype == OQ_BF16)
         hipLaunchKernelGGL((norm_bwd_kernel<bf16_t>), dim3(grid), dim3(bt), 0, st, (const bf16_t*)x, (const bf16_t*)gy,
-                           rows, cols, w, rstd, mean, is_layernorm, (bf16_t*)gx, workspace, gb ? 1 : 0);
+                           rows, cols, w, rstd, mean, is_layernorm, (bf16_t*)gx, workspace, gb ? 1 : 0, (const bf16_t*)gx_addend);
     else {
         oq_set_error("oq_norm_bwd: dtype %d", dtype);
         return OQ_E_UNSUPPORTED;

@@ -148,6 +148,6 @@ class QuantLlamaDecoderLayer(QuantBlockMixin, nn.Module):
         hidden_states, _, _ = self.self_attn(hidden_states=h, attention_mask=attention_mask, position_ids=position_ids,
                                              past_key_value=past_key_value, output_attentions=output_attentions,
                                              use_cache=use_cache, residual=residual)
-        h = self.post_attention_layernorm(hidden_states)
-        hidden_states = self.mlp(h, residual=hidden_states)
+        h, res = self.post_attention_layernorm.forward_with_residual(hidden_states)   # residual-path grad joins in norm bwd
+        hidden_states = self.mlp(h, residual=res)
         return (hidden_states,)

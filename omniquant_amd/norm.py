@@ -25,6 +25,14 @@ class OmniLayerNorm(nn.Module):
             weight, bias = self.weight, self.bias
         return ops.NormFn.apply(x, weight, bias, self.eps, True)
 
+    def forward_with_residual(self, x):
+        """(norm(x), x) as one autograd node: see ops.NormResidualFn."""
+        if self.use_temporary_parameter:
+            weight, bias = self.temp_weight, self.temp_bias
+        else:
+            weight, bias = self.weight, self.bias
+        return ops.NormResidualFn.apply(x, weight, bias, self.eps, True)
+
     def set_quant_state(self, use_weight_quant, use_act_quant):
         self.use_act_quant = use_act_quant
 
@@ -43,3 +51,11 @@ class OmniLlamaRMSNorm(nn.Module):
         else:
             weight, bias = self.weight, self.bias if hasattr(self, "bias") else None
         return ops.NormFn.apply(hidden_states, weight, bias, self.variance_epsilon, False)
+
+    def forward_with_residual(self, hidden_states):
+        """(norm(x), x) as one autograd node: see ops.NormResidualFn."""
+        if self.use_temporary_parameter:
+            weight, bias = self.temp_weight, self.temp_bias
+        else:
+            weight, bias = self.weight, self.bias if hasattr(self, "bias") else None
+        return ops.NormResidualFn.apply(hidden_states, weight, bias, self.variance_epsilon, False)

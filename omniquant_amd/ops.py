@@ -353,38 +353,68 @@ class AttnPVFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------
 # norms and glue
 # ------------------------------------------------------------------------------------------------------
+def _norm_forward(ctx, x, w, b, eps, is_ln):
+    x = x.contiguous()
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    w32, b32 = _f32(w), _f32(b)
+    y = torch.empty_like(x)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if is_ln else None
+    C.call("oq_norm_fwd", C.ptr(x), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), float(eps), int(is_ln),
+           C.ptr(y), C.fptr(rstd), C.fptr(mean), C.stream())
+    ctx.save_for_backward(x, w32, rstd, mean)
+    ctx.is_ln, ctx.has_b = is_ln, b is not None
+    return x, y
+
+
+def _norm_backward(ctx, gy, gpass):
+    x, w32, rstd, mean = ctx.saved_tensors
+    gy = gy.contiguous()
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    gx = torch.empty_like(x)
+    gw = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    gb = torch.empty((cols,), dtype=torch.float32, device=x.device) if (ctx.has_b and ctx.needs_input_grad[2]) else None
+    ws_n = C.size_call("oq_norm_bwd_workspace", rows, cols)
+    ws = torch.empty((ws_n,), dtype=torch.float32, device=x.device)
+    if gpass is not None:
+        gpass = gpass.contiguous()
+        if gpass.dtype != x.dtype:
+            gpass = gpass.to(x.dtype)
+    C.call("oq_norm_bwd", C.ptr(x), C.ptr(gy), C.dt(x), rows, cols, C.fptr(w32), C.fptr(rstd), C.fptr(mean),
+           int(ctx.is_ln), C.ptr(gx), C.fptr(gw), C.fptr(gb), C.ptr(gpass), C.fptr(ws), ws_n, C.stream())
+    return gx, (gw if ctx.needs_input_grad[1] else None), gb, None, None
+
+
 class NormFn(torch.autograd.Function):
     """OmniLlamaRMSNorm / OmniLayerNorm (quantize/omni_norm.py:26-34,52-63)."""
 
     @staticmethod
     def forward(ctx, x, w, b, eps, is_ln):
-        x = x.contiguous()
-        cols = x.shape[-1]
-        rows = x.numel() // cols
-        w32, b32 = _f32(w), _f32(b)
-        y = torch.empty_like(x)
-        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
-        mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if is_ln else None
-        C.call("oq_norm_fwd", C.ptr(x), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), float(eps), int(is_ln),
-               C.ptr(y), C.fptr(rstd), C.fptr(mean), C.stream())
-        ctx.save_for_backward(x, w32, rstd, mean)
-        ctx.is_ln, ctx.has_b = is_ln, b is not None
-        return y
+        return _norm_forward(ctx, x, w, b, eps, is_ln)[1]
 
     @staticmethod
     def backward(ctx, gy):
-        x, w32, rstd, mean = ctx.saved_tensors
-        gy = gy.contiguous()
-        cols = x.shape[-1]
-        rows = x.numel() // cols
-        gx = torch.empty_like(x)
-        gw = torch.empty((cols,), dtype=torch.float32, device=x.device)
-        gb = torch.empty((cols,), dtype=torch.float32, device=x.device) if (ctx.has_b and ctx.needs_input_grad[2]) else None
-        ws_n = C.size_call("oq_norm_bwd_workspace", rows, cols)
-        ws = torch.empty((ws_n,), dtype=torch.float32, device=x.device)
-        C.call("oq_norm_bwd", C.ptr(x), C.ptr(gy), C.dt(x), rows, cols, C.fptr(w32), C.fptr(rstd), C.fptr(mean),
-               int(ctx.is_ln), C.ptr(gx), C.fptr(gw), C.fptr(gb), C.fptr(ws), ws_n, C.stream())
-        return gx, (gw if ctx.needs_input_grad[1] else None), gb, None, None
+        return _norm_backward(ctx, gy, None)
+
+
+class NormResidualFn(torch.autograd.Function):
+    """(norm(x), x): the same norm, plus the input handed through for the block's residual path
+    (models/int_llama_layer.py:248-264: residual = hidden; hidden = norm(hidden); ...; hidden = residual + mlp).
+    One autograd node, so the gradient arriving on the residual path is added to the norm's input gradient inside
+    the backward kernel (oq_norm_bwd gx_addend) instead of by a separate `add` launch."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, is_ln):
+        xc, y = _norm_forward(ctx, x, w, b, eps, is_ln)
+        return y, xc.view_as(xc)
+
+    @staticmethod
+    def backward(ctx, gy, gpass):
+        if gy is None:          # only the residual path was used
+            return gpass, None, None, None, None
+        return _norm_backward(ctx, gy, gpass)
 
 
 class RopeFn(torch.autograd.Function):

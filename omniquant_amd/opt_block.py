@@ -103,8 +103,10 @@ class QuantOPTDecoderLayer(QuantBlockMixin, nn.Module):
                                              residual=residual)      # residual add folded into out_proj's GEMM store
         if not self.do_layer_norm_before:
             hidden_states = self.self_attn_layer_norm(hidden_states)
-        residual = hidden_states
-        h = self.final_layer_norm(hidden_states) if self.do_layer_norm_before else hidden_states
+        if self.do_layer_norm_before:
+            h, residual = self.final_layer_norm.forward_with_residual(hidden_states)    # residual-path grad joins in norm bwd
+        else:
+            h = residual = hidden_states
         hidden_states = self.fc2(ops.ReluFn.apply(self.fc1(h)), residual=residual)
         if not self.do_layer_norm_before:
             hidden_states = self.final_layer_norm(hidden_states)
