@@ -153,7 +153,7 @@ def pmc_traffic(name):
         return None
 
 
-def cpu_baseline(name, n_steps=1):
+def cpu_baseline(name, n_steps=2):
     """CPU baseline: the oracle (pure-PyTorch fp32 restatement of the reference loop, pinned to the reference by the
     golden fixtures) timed on this box's host cores on a bounded sample of the SAME workload.  Baseline only."""
     from oracle import ref_cpu as R
@@ -186,7 +186,7 @@ def cpu_baseline(name, n_steps=1):
         R.train_step(blk, opt, x[j:j + 1], tgt[j:j + 1], mask, pos)
     dt = time.time() - t0
     return dict(value=n_steps / dt, unit="sample-steps/s", cores=cores, kind="port",
-                sample=f"{n_steps} sample-steps of one {arch} block (T={SEQLEN}, fp32, {cores} threads), no warm-up")
+                sample=f"{n_steps} sample-steps of one {arch} block (T={SEQLEN}, fp32, {cores} threads; ~8 s each on the GPU box), no warm-up")
 
 
 def main():
