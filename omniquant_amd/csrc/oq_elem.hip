@@ -253,7 +253,7 @@ __global__ void cast_kernel(const TS* x, TD* y, int64_t n) {
 // column sums (bias gradients), deterministic: grid (column groups of 512, row slabs); a lane owns 8 columns (16-byte
 // loads), the 4 waves of a block interleave the slab's rows and combine through LDS; slab partials go to the workspace
 // and colsum_final_kernel adds them in slab order (no atomics: the order of a float sum must not depend on timing).
-constexpr int COLSUM_MAX_SLABS = 64;
+constexpr int COLSUM_MAX_SLABS = 128;
 
 template <typename T>
 __global__ void __launch_bounds__(256) colsum_partial_kernel(const T* x, int64_t rows, int64_t cols, float* ws) {
@@ -430,7 +430,7 @@ extern "C" int oq_cast(const void* x, int src_dtype, void* y, int dst_dtype, int
 }
 
 static int colsum_slabs(int64_t rows) {
-    int64_t s = rows / 64;
+    int64_t s = rows / 16;          // many small slabs: the partial kernel is latency-bound below ~2 workgroups per CU
     return (int)(s < 1 ? 1 : (s > COLSUM_MAX_SLABS ? COLSUM_MAX_SLABS : s));
 }
 
