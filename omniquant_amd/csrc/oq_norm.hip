@@ -19,18 +19,18 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     return a;
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ void __launch_bounds__(1024) norm_fwd_kernel(const T* x, int64_t rows, int64_t cols, const float* w,
                                                         const float* b, float eps, int ln, T* y, float* rstd_out,
                                                         float* mean_out) {
     __shared__ float red[16];
     const int t = threadIdx.x, BT = blockDim.x;
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
-        float v[MAXCH][8];
-        bool valid[MAXCH];
+        float v[NCH][8];
+        bool valid[NCH];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             valid[j] = c0 < cols;
             if (valid[j]) {
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(1024) norm_fwd_kernel(const T* x, int64_t rows
             mean = s / (float)cols;
             float s2 = 0.f;
 #pragma unroll
-            for (int j = 0; j < MAXCH; ++j)
+            for (int j = 0; j < NCH; ++j)
                 if (valid[j]) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { const float d = v[j][i] - mean; s2 += d * d; }
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(1024) norm_fwd_kernel(const T* x, int64_t rows
             if (mean_out) mean_out[r] = mean;
         }
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             if (!valid[j]) continue;
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             float o[8], wv[8], bv[8];
@@ -81,20 +81,20 @@ __global__ void __launch_bounds__(1024) norm_fwd_kernel(const T* x, int64_t rows
     }
 }
 
-template <typename T>
+template <typename T, int NCH>
 __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, int64_t rows, int64_t cols,
                                                        const float* w, const float* rstd_in, const float* mean_in,
                                                        int ln, T* gx, float* ws, int want_b, const T* gx_add) {
     __shared__ float red[16];
     const int t = threadIdx.x, BT = blockDim.x;
-    float aw[MAXCH][8], ab[MAXCH][8];
+    float aw[NCH][8], ab[NCH][8];
 #pragma unroll
-    for (int j = 0; j < MAXCH; ++j)
+    for (int j = 0; j < NCH; ++j)
 #pragma unroll
         for (int i = 0; i < 8; ++i) { aw[j][i] = 0.f; ab[j][i] = 0.f; }
-    float wv[MAXCH][8];                       // the norm weight of this thread's columns: loaded once, as vectors
+    float wv[NCH][8];                       // the norm weight of this thread's columns: loaded once, as vectors
 #pragma unroll
-    for (int j = 0; j < MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         const int64_t c0 = ((int64_t)j * BT + t) * 8;
         if (c0 < cols) {
             Vec8<float>::load(w + c0, wv[j]);
@@ -106,11 +106,11 @@ __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, 
     for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float rstd = rstd_in[r];
         const float mean = (ln && mean_in) ? mean_in[r] : 0.f;
-        float xh[MAXCH][8], gh[MAXCH][8];   // normalised x, and gy*w
-        bool valid[MAXCH];
+        float xh[NCH][8], gh[NCH][8];   // normalised x, and gy*w
+        bool valid[NCH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             valid[j] = c0 < cols;
             if (valid[j]) {
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, 
         s2 = block_sum(s2, red) / (float)cols;
         s1 = ln ? block_sum(s1, red) / (float)cols : 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXCH; ++j) {
+        for (int j = 0; j < NCH; ++j) {
             if (!valid[j]) continue;
             const int64_t c0 = ((int64_t)j * BT + t) * 8;
             float o[8];
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(512) norm_bwd_kernel(const T* x, const T* gy, 
     float* pw = ws + (int64_t)blockIdx.x * cols;
     float* pb = ws + ((int64_t)gridDim.x + blockIdx.x) * cols;
 #pragma unroll
-    for (int j = 0; j < MAXCH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         const int64_t c0 = ((int64_t)j * BT + t) * 8;
         if (c0 < cols) {
             Vec8<float>::store(pw + c0, aw[j]);
@@ -212,13 +212,16 @@ extern "C" int oq_norm_fwd(const void* x, int dtype, int64_t rows, int64_t cols,
     const int bt = norm_threads(cols);
     const int64_t grid = rows < 8192 ? rows : 8192;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == OQ_F32)
-        hipLaunchKernelGGL((norm_fwd_kernel<float>), dim3(grid), dim3(bt), 0, st, (const float*)x, rows, cols, w, b, eps,
-                           is_layernorm, (float*)y, rstd, mean);
-    else if (dtype == OQ_BF16)
-        hipLaunchKernelGGL((norm_fwd_kernel<bf16_t>), dim3(grid), dim3(bt), 0, st, (const bf16_t*)x, rows, cols, w, b, eps,
-                           is_layernorm, (bf16_t*)y, rstd, mean);
-    else {
+    // chunks of 8 elements per thread: 1, 2 or 4 (a template parameter: the row lives in registers, and sizing every
+    // instantiation for 4 chunks cost half the occupancy at hidden sizes <= 4096)
+    const int64_t per = ((cols + 7) / 8 + bt - 1) / bt;
+    const int nch = per <= 1 ? 1 : (per <= 2 ? 2 : 4);
+#define NORM_FWD(T_, N_) hipLaunchKernelGGL((norm_fwd_kernel<T_, N_>), dim3(grid), dim3(bt), 0, st, (const T_*)x, rows, cols, w, b, eps, is_layernorm, (T_*)y, rstd, mean)
+    if (dtype == OQ_F32) {
+        if (nch == 1) NORM_FWD(float, 1); else if (nch == 2) NORM_FWD(float, 2); else NORM_FWD(float, 4);
+    } else if (dtype == OQ_BF16) {
+        if (nch == 1) NORM_FWD(bf16_t, 1); else if (nch == 2) NORM_FWD(bf16_t, 2); else NORM_FWD(bf16_t, 4);
+    } else {
         oq_set_error("oq_norm_fwd: dtype %d", dtype);
         return OQ_E_UNSUPPORTED;
     }
@@ -238,13 +241,14 @@ extern "C" int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t row
     OQ_CHECK_ARG(gw && workspace && workspace_floats >= 2 * grid * cols, "oq_norm_bwd: gw and a workspace of %lld floats are required",
                  (long long)(2 * grid * cols));
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == OQ_F32)
-        hipLaunchKernelGGL((norm_bwd_kernel<float>), dim3(grid), dim3(bt), 0, st, (const float*)x, (const float*)gy, rows,
-                           cols, w, rstd, mean, is_layernorm, (float*)gx, workspace, gb ? 1 : 0, (const float*)gx_addend);
-    else if (dtype == OQ_BF16)
-        hipLaunchKernelGGL((norm_bwd_kernel<bf16_t>), dim3(grid), dim3(bt), 0, st, (const bf16_t*)x, (const bf16_t*)gy,
-                           rows, cols, w, rstd, mean, is_layernorm, (bf16_t*)gx, workspace, gb ? 1 : 0, (const bf16_t*)gx_addend);
-    else {
+    const int64_t per = ((cols + 7) / 8 + bt - 1) / bt;
+    const int nch = per <= 1 ? 1 : (per <= 2 ? 2 : 4);
+#define NORM_BWD(T_, N_) hipLaunchKernelGGL((norm_bwd_kernel<T_, N_>), dim3(grid), dim3(bt), 0, st, (const T_*)x, (const T_*)gy, rows, cols, w, rstd, mean, is_layernorm, (T_*)gx, workspace, gb ? 1 : 0, (const T_*)gx_addend)
+    if (dtype == OQ_F32) {
+        if (nch == 1) NORM_BWD(float, 1); else if (nch == 2) NORM_BWD(float, 2); else NORM_BWD(float, 4);
+    } else if (dtype == OQ_BF16) {
+        if (nch == 1) NORM_BWD(bf16_t, 1); else if (nch == 2) NORM_BWD(bf16_t, 2); else NORM_BWD(bf16_t, 4);
+    } else {
         oq_set_error("oq_norm_bwd: dtype %d", dtype);
         return OQ_E_UNSUPPORTED;
     }
