@@ -250,7 +250,7 @@ def main():
                        "calib_samples": n, "blocks_per_gpu": 1, "sharding": f"layers x{world}",
                        "per_gpu_sample_steps_per_sec": value / world, "last_loss": loss,
                        "linear_tflop_per_step": flops / 1e12},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (fprop+dgrad+wgrad of the fake-quant linears)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_p3_kernel (fprop+dgrad+wgrad of the fake-quant linears)",
                          "achieved": roof["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(a.config),
                          "avg_launch_ms": roof["avg_launch_ms"], "launches_per_step": roof["launches_per_step"],
