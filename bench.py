@@ -8,10 +8,13 @@ teacher output, backward, grad-norm and AdamW -- all on the HIP path, replayed f
 
     python bench.py --gpus N --steps K --warmup W [--config llama-7b-w4a4|llama-7b-w3a16g128|...]
 
-N>1: launched by torch.distributed.run, one rank per GPU; every rank calibrates its own decoder block
-(layer-sharded, weak scaling); there is no collective inside the step loop (the only exchange of the sharded
-engine is the boundary-activation send/recv before and the parameter gather after the loop).
-Prints ONE JSON line on rank 0.
+Two timed regions, both bracketed by barrier + synchronize and reduced with MAX over ranks:
+  1. the contract's region: W warm-up + exactly K sample-steps per rank (`value`, `ms_per_step`).  There is no
+     collective inside the step loop of the layer-sharded engine, so every rank steps its own block;
+  2. `end_to_end`: the REAL sharded engine (omniquant_amd.parallel.calibrate_sharded over world x blocks-per-rank
+     layers): streamed teacher pre-pass with RCCL send/recv of the boundary activation bank, per-layer teacher pass,
+     hipGraph capture, the sample-steps, fold, propagate and the final parameter gather.
+N>1: launched by torch.distributed.run, one rank per GPU.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -141,19 +144,28 @@ def gemm_roofline(runner, quant_inps, fp_inps, cfg, n_prof=3):
                 gemm_ms_per_step=1e3 * all_t / n_prof, linear_gemm_ms_per_step=1e3 * tot_t / n_prof)
 
 
-def pmc_traffic(name):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and
-    WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); counters
-    cannot be read from inside this process, so the number comes from profiles/ and is null for an unprofiled config."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_gemm_traffic.json")
+PROFILE_COUNTERS = "r2_gemm_counters.json"
+ROOFLINE_KERNEL = "gemm_bf16_p3_kernel"
+
+
+def pmc_counters(name):
+    """rocprofv3 PMC results of the dominant kernel from the committed passes (profiles/README.md): HBM-side bytes per
+    launch (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950) and the MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES)).  Hardware counters
+    cannot be read from inside this process, so the numbers come from profiles/ -- and ONLY when that file was
+    collected for this config and for the kernel the run reports; otherwise both are null."""
+    path = os.path.join(ROOT, "profiles", PROFILE_COUNTERS)
     try:
         with open(path) as f:
-            return json.load(f).get(name, {}).get("bytes_per_launch")
-    except OSError:
-        return None
+            ent = json.load(f).get(name)
+    except (OSError, ValueError):
+        return None, None
+    if not ent or ent.get("kernel") != ROOFLINE_KERNEL:
+        return None, None
+    return ent.get("bytes_per_launch"), ent.get("mfma_busy_frac")
 
 
-def cpu_baseline(name, n_steps=2):
+def cpu_baseline(name, n_steps=3, n_warm=1):
     """CPU baseline: the oracle (pure-PyTorch fp32 restatement of the reference loop, pinned to the reference by the
     golden fixtures) timed on this box's host cores on a bounded sample of the SAME workload.  Baseline only."""
     from oracle import ref_cpu as R
@@ -176,27 +188,90 @@ def cpu_baseline(name, n_steps=2):
         sc, sh = S.synth_act_stats(cfg, 1)
         blk.register_let(sc, sh, alpha, 0, "model.layers" if cfg.family == "llama" else "model.decoder.layers")
     opt = R.AdamW([{"params": blk.let_params(), "lr": let_lr}, {"params": blk.lwc_params(), "lr": 1e-2}])
-    x = S.make_calib_inputs(n_steps, SEQLEN, cfg.hidden_size, dtype=torch.float32)
+    n_all = n_steps + n_warm
+    x = S.make_calib_inputs(n_all, SEQLEN, cfg.hidden_size, dtype=torch.float32)
     mask = S.causal_mask(SEQLEN)
     pos = torch.arange(SEQLEN)[None]
     with torch.no_grad():
-        tgt = torch.stack([blk.forward(x[j:j + 1], mask, pos, None, False)[0] for j in range(n_steps)])
+        tgt = torch.stack([blk.forward(x[j:j + 1], mask, pos, None, False)[0] for j in range(n_all)])
+    for j in range(n_warm):
+        R.train_step(blk, opt, x[j:j + 1], tgt[j:j + 1], mask, pos)
     t0 = time.time()
-    for j in range(n_steps):
+    for j in range(n_warm, n_all):
         R.train_step(blk, opt, x[j:j + 1], tgt[j:j + 1], mask, pos)
     dt = time.time() - t0
     return dict(value=n_steps / dt, unit="sample-steps/s", cores=cores, kind="port",
-                sample=f"{n_steps} sample-steps of one {arch} block (T={SEQLEN}, fp32, {cores} threads; ~8 s each on the GPU box), no warm-up")
+                sample=f"{n_warm} warm-up + {n_steps} timed sample-steps of one {arch} block (T={SEQLEN}, fp32 oracle, "
+                       f"{cores} threads, {dt / n_steps:.1f} s per step)")
+
+
+def end_to_end(name, rank, world, dev, dist, n_samples, blocks_per_rank, chunk):
+    """Second timed region: the real layer-sharded engine on world x blocks_per_rank synthetic layers.  Returns the
+    wall time (MAX over ranks) of calibrate_sharded -- teacher pre-pass pipeline, calibration of every owned block
+    (1 epoch x n_samples sample-steps each, hipGraph-replayed), fold, propagate, gather of the learned parameters."""
+    from omniquant_amd import synthetic as S
+    from omniquant_amd.calibrate import default_args
+    from omniquant_amd.parallel import calibrate_sharded, hip_callables, shard_bounds
+    arch, wbits, abits, group, lwc, let, let_lr, alpha, aug = CONFIGS[name]
+    cfg = S.make_config(arch)
+    L = world * blocks_per_rank
+    args = default_args(wbits=wbits, abits=abits, group_size=group, lwc=lwc, let=let, let_lr=let_lr, alpha=alpha,
+                        aug_loss=aug, net=arch, nsamples=n_samples, epochs=1)
+    lo, hi = shard_bounds(L, world, rank)
+    layers = [S.make_layer(cfg, seed=100 + i, device=dev) if lo <= i < hi else None for i in range(L)]
+    H = cfg.hidden_size
+    if rank == 0:
+        g = torch.Generator(device=dev).manual_seed(11)
+        ch = torch.exp(0.5 * torch.randn(H, device=dev, generator=g))
+        inps = (torch.randn(n_samples, SEQLEN, H, device=dev, generator=g) * ch).to(torch.bfloat16)
+    else:
+        inps = torch.empty(n_samples, SEQLEN, H, device=dev, dtype=torch.bfloat16)
+    mask = S.causal_mask(SEQLEN, dev)
+    pos = torch.arange(SEQLEN, device=dev)[None]
+    sc, sh = S.synth_act_stats(cfg, L) if let else (None, None)
+    teacher, calib = hip_callables(layers, cfg, args, mask, pos, sc, sh, None, torch.bfloat16, True)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    if dist is not None:
+        merged, _ = calibrate_sharded(L, inps, teacher, calib, chunk=chunk)
+    else:
+        merged = calib(0, L, inps, inps.clone())
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    if rank == 0:
+        assert merged is not None and sorted(merged.keys()) == list(range(L)), "gather lost a layer"
+    steps = L * n_samples
+    return dict(value=steps / dt, unit="sample-steps/s", wall_s=dt, layers=L, blocks_per_rank=blocks_per_rank,
+                calib_samples=n_samples, epochs=1, boundary_message_samples=chunk,
+                includes="streamed teacher pre-pass (RCCL send/recv of the boundary bank between ranks), per-layer teacher "
+                         "pass, hipGraph capture, sample-steps, fold, propagate, final parameter gather")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=8)
+    # defaults: ~1 s of warm-up and ~4 s timed at the default config, so clocks and the driver's GPU-busy sampling see
+    # the steady state (128 steps were 0.5 s)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--config", default="llama-7b-w4a4", choices=list(CONFIGS))
     ap.add_argument("--nsamples", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--e2e-samples", type=int, default=16, help="calibration samples of the end-to-end region")
+    ap.add_argument("--blocks-per-rank", type=int, default=1, help="decoder blocks per rank in the end-to-end region")
+    ap.add_argument("--boundary-chunk", type=int, default=4, help="samples per boundary message of the teacher pre-pass")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -239,24 +314,33 @@ def main():
     assert loss == loss, "NaN loss in the timed region"
 
     roof = gemm_roofline(runner, quant_inps, fp_inps, cfg)
+    e2e = None
+    if not a.no_end_to_end and not a.config.startswith("opt"):
+        del runner, opt, q
+        torch.cuda.empty_cache()
+        e2e = end_to_end(a.config, rank, world, dev, dist, a.e2e_samples, a.blocks_per_rank, a.boundary_chunk)
     if rank == 0:
         flops, P = linear_flops(cfg, SEQLEN)
         value = world * a.steps / dt
+        traffic, mfma_busy = pmc_counters(a.config)
         out = {
             "metric": "calibration_sample_steps_per_sec", "value": value, "unit": "sample-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": WORKLOAD[a.config], "name": a.config, "seq_len": SEQLEN, "batch_size": 1,
                        "calib_samples": n, "blocks_per_gpu": 1, "sharding": f"layers x{world}",
+                       "n_ranks_seen": int(dist.get_world_size()) if dist is not None else 1,
                        "per_gpu_sample_steps_per_sec": value / world, "last_loss": loss,
                        "linear_tflop_per_step": flops / 1e12},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_p3_kernel (fprop+dgrad+wgrad of the fake-quant linears)",
+            "roofline": {"bound": "mfma", "kernel": ROOFLINE_KERNEL + " (fprop+dgrad+wgrad of the fake-quant linears)",
                          "achieved": roof["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic(a.config),
+                         "frac": roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "mfma_busy_frac": mfma_busy,
                          "avg_launch_ms": roof["avg_launch_ms"], "launches_per_step": roof["launches_per_step"],
                          "linear_gemm_ms_per_step": roof["linear_gemm_ms_per_step"],
                          "all_gemm_ms_per_step": roof["gemm_ms_per_step"]},
         }
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.config)
         print(json.dumps(out), flush=True)

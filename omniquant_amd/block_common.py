@@ -31,6 +31,22 @@ class QuantBlockMixin:
     def _quant_linears(self):
         return [m for m in self.modules() if isinstance(m, QuantLinear)]
 
+    # ---- block boundary dtype -------------------------------------------------------------------------------------
+    # The kernels compute in bfloat16 (MFMA bf16) or float32 (parity mode).  A float16 hidden state -- what the
+    # reference's fp16 model hands to the layers it gets back from omniquant() (main.py evaluate) -- is converted to the
+    # compute dtype on entry and the result is returned in float16 again, so the returned model keeps its dtype contract.
+    def _enter(self, hidden_states):
+        from . import ops
+        if hidden_states.dtype == torch.float16:
+            cd = self.compute_dtype if self.compute_dtype in (torch.bfloat16, torch.float32) else torch.bfloat16
+            return ops.cast(hidden_states, cd), torch.float16
+        return hidden_states, None
+
+    @staticmethod
+    def _leave(hidden_states, back):
+        from . import ops
+        return hidden_states if back is None else ops.cast(hidden_states, back)
+
     def _truncate_scales(self):
         arena = self.__dict__.get("_arena_truncate")
         if arena is not None:
@@ -86,6 +102,13 @@ class QuantBlockMixin:
         (same kernels, same values, different issue order)."""
         nm = self._let_names()
         from . import ops
+        hidden = self.qkv_smooth_scale.numel()
+        for key in ("q", "k", "v"):
+            if nm[key].out_features != hidden:
+                # smooth_q_k / smooth_fc_fc pair q, k, v and o row by row (models/transformation.py:44-69): the reference
+                # dies on a broadcast error for grouped-query attention; fail as loudly instead of reading out of bounds
+                raise NotImplementedError(f"LET with {key}_proj.out_features = {nm[key].out_features} != hidden size "
+                                          f"{hidden}: grouped-query attention has no LET (use --lwc only)")
         specs = L.block_let_specs(nm, self, None)
         f = self._f32c
         mlp = set(nm["fc1"]) | {nm["last"]} if lazy_mlp else set()

@@ -273,7 +273,8 @@ def calibrate_layers(layers, config, args, inps, attention_mask, position_ids=No
     fp_inps = inps.to(compute_dtype).clone()
     fp_inps_2 = inps.to(compute_dtype).clone() if args.aug_loss else None
     mask = attention_mask.float().contiguous() if attention_mask is not None else None
-    resume = torch.load(args.resume) if getattr(args, "resume", None) else {}
+    # omni_parameters.pth is {layer_idx: OrderedDict(name -> fp16 tensor)}: loadable without unpickling code
+    resume = torch.load(args.resume, map_location="cpu", weights_only=True) if getattr(args, "resume", None) else {}
     omni_parameters = dict(resume) if resume else {}
     all_losses, qlayers = [], []
     for i, layer in enumerate(layers):

@@ -317,7 +317,12 @@ __global__ void __launch_bounds__(512) fq_fwd_kernel(FQ p) {
                 q = make_qp(h, l, lwc, cup[j], clow[j], p.nbits, p.symmetric, p.inv_q, &inv_s);
             }
             float yv[8];
-            if (q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad[j] == 0.f) {
+            if (p.nbits >= 16) {
+                // identity grid: the reference's quantizer returns its input unchanged for n_bits >= 16
+                // (quantize/quantizer.py:109-110); only the fused LET transform / w @ shift of this kernel remain
+#pragma unroll
+                for (int i = 0; i < 8; ++i) yv[i] = x[j][i];
+            } else if (q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad[j] == 0.f) {
                 // regular segment (finite non-zero scale, no NaN): no special values can appear below
                 // rne(x / s) as rne(x * (1/s)); the (rare) lanes whose product lies within ~2 ulp of a half-integer redo
                 // the exact division -- tested for the whole chunk with ONE wave-uniform branch
@@ -394,6 +399,7 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
     const bool need_row = LET && (p.g_row_div || p.g_row_mul);
     const bool need_sh = LET && p.g_shift;
     const bool need_tie = p.gx || need_cm;
+    const bool ident = p.nbits >= 16;      // identity grid (see fq_fwd_kernel): y = x', so dL/dx' = G and nothing else
 
     constexpr int NACC = LET ? CH : 1;
     float acc_cm[NACC][8], acc_sh[NACC][8], cmv[NACC][8];
@@ -509,7 +515,7 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
                     f32x2 qv;
                     qv[0] = __builtin_amdgcn_fmed3f(u[0], 0.f, Q);
                     qv[1] = __builtin_amdgcn_fmed3f(u[1], 0.f, Q);
-                    const bool in0 = qv[0] == u[0], in1 = qv[1] == u[1];      // inside [0, Q] (false for NaN)
+                    const bool in0 = ident || qv[0] == u[0], in1 = ident || qv[1] == u[1];   // inside [0, Q] (false for NaN)
                     // block-wide sums (whole-row segments, row factors) skip the surplus lanes; group-wide sums of the
                     // short-segment mode do not: a surplus GROUP recomputes the last segment completely
                     const f32x2 Gr = FULL ? gv : gv * live2;
@@ -573,8 +579,12 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
             for (int j = 0; j < CH; ++j) { gs[j] = v[0]; nhi[j] = v[1]; nlo[j] = v[2]; }
             acc_rm = v[3];
         }
+        if (ident) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) gs[j] = 0.f;        // no scale in the identity grid: no LWC / tie terms
+        }
         // ---- d s / d hi', d s / d lo'  (hi' = su*hi, lo' = sl*lo), LWC gradients, tie terms ------
-        const bool any_tie = need_tie && wave_tie;                                      // wave-uniform
+        const bool any_tie = need_tie && wave_tie && !ident;                            // wave-uniform
         float row_tie = 0.f;        // grouped segments: sum over this thread's segments of the tie part of g_row_mul
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
@@ -723,7 +733,7 @@ void row_geometry(int64_t cols, int pref, int* ch, int* bt) {
 int check_shape(const char* fn, int64_t rows, int64_t cols, int64_t seg, int nbits) {
     OQ_CHECK_ARG(rows > 0 && cols > 0 && seg > 0, "%s: empty shape rows=%lld cols=%lld seg=%lld", fn, (long long)rows,
                  (long long)cols, (long long)seg);
-    OQ_CHECK_ARG(nbits >= 2 && nbits < 16, "%s: bitwidth %d not supported (2..15)", fn, nbits);
+    OQ_CHECK_ARG(nbits >= 2 && nbits <= 16, "%s: bitwidth %d not supported (2..15, 16 = identity grid)", fn, nbits);
     OQ_CHECK_ARG(cols % seg == 0, "%s: cols %lld not a multiple of seg %lld (ragged groups unsupported)", fn,
                  (long long)cols, (long long)seg);
     OQ_CHECK_ARG(seg % 8 == 0, "%s: seg %lld must be a multiple of 8", fn, (long long)seg);
@@ -735,6 +745,146 @@ int check_shape(const char* fn, int64_t rows, int64_t cols, int64_t seg, int nbi
     }
     OQ_CHECK_ARG(cols <= 8 * 512 * 8, "%s: cols %lld exceeds %d", fn, (long long)cols, 8 * 512 * 8);
     return OQ_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// generic-segment path: ANY segment length / row length, last segment of a row zero-padded to the full segment
+// ---------------------------------------------------------------------------------------------------
+// Reference: quantize/quantizer.py:64-69 (deficiency), :85-87 / :125-128 (zero-pad, reshape to [-1, group]) and
+// :103-104 (the pad is cut off again).  One wave per segment, scalar element accesses: this is the shape-complete
+// path for the segmentations the vector kernels above do not take (in_features % group_size != 0, groups that are not
+// 8 * 2^k wide) -- not a hot path.  Same helpers (make_qp, rne_div) as the vector kernels, so values agree bit for bit
+// where both apply.  The zero padding takes part in amax / amin (and in their tie counts in the backward); the padded
+// outputs do not exist, so their upstream gradient is zero.  No LET arguments here.
+template <typename TIN, typename TOUT>
+__global__ void __launch_bounds__(256) fq_generic_fwd_kernel(FQ p, int64_t nsr /* segments per row */) {
+    const int lane = threadIdx.x & 63;
+    const int64_t sidx = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (sidx >= p.rows * nsr) return;                        // wave-uniform
+    const int64_t r = sidx / nsr, c0 = (sidx % nsr) * p.seg;
+    const int64_t valid = p.cols - c0 < p.seg ? p.cols - c0 : p.seg;
+    const TIN* w = reinterpret_cast<const TIN*>(p.w) + r * p.cols + c0;
+    TOUT* y = reinterpret_cast<TOUT*>(p.y) + r * p.cols + c0;
+    const float Q = (float)((1 << p.nbits) - 1);
+    float hi = -INFINITY, lo = INFINITY, bad = 0.f;
+    for (int64_t i = lane; i < valid; i += 64) {
+        const float x = ld1(w + i);
+        hi = vmax(hi, x);
+        lo = vmin(lo, x);
+        if (x != x) bad = 1.f;
+    }
+    hi = wave_max(hi);
+    lo = wave_min(lo);
+    bad = wave_max(bad);
+    if (valid < p.seg) { hi = fmaxf(hi, 0.f); lo = fminf(lo, 0.f); }
+    if (bad != 0.f) { hi = NAN; lo = NAN; }
+    const bool lwc = p.up != nullptr;
+    float inv_s = 0.f;
+    const QP q = make_qp(hi, lo, lwc, lwc ? p.up[sidx] : 0.f, lwc ? p.low[sidx] : 0.f, p.nbits, p.symmetric, p.inv_q, &inv_s);
+    const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad == 0.f;
+    for (int64_t i = lane; i < valid; i += 64) {
+        const float x = ld1(w + i);
+        float yv;
+        if (p.nbits >= 16) {
+            yv = x;
+        } else if (regular) {
+            float tq;
+            const float rq = rne_div(x, q.s, inv_s, &tq);
+            yv = (__builtin_amdgcn_fmed3f(rq + q.z, 0.f, Q) - q.z) * q.s;
+        } else {
+            float v = rne_ste(x / q.s) + q.z;
+            v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
+            yv = (v - q.z) * q.s;
+        }
+        st1(y + i, yv);
+    }
+    if (lane == 0) {
+        p.scale[sidx] = q.s;
+        p.zp[sidx] = q.z;
+        p.xmin[sidx] = lo;
+        p.xmax[sidx] = hi;
+    }
+}
+
+template <typename TIN, typename TG>
+__global__ void __launch_bounds__(256) fq_generic_bwd_kernel(FQ p, int64_t nsr) {
+    const int lane = threadIdx.x & 63;
+    const int64_t sidx = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (sidx >= p.rows * nsr) return;
+    const int64_t r = sidx / nsr, c0 = (sidx % nsr) * p.seg;
+    const int64_t valid = p.cols - c0 < p.seg ? p.cols - c0 : p.seg;
+    const TIN* w = reinterpret_cast<const TIN*>(p.w) + r * p.cols + c0;
+    const TG* g = reinterpret_cast<const TG*>(p.g) + r * p.cols + c0;
+    const float Q = (float)((1 << p.nbits) - 1);
+    const bool lwc = p.up != nullptr, ident = p.nbits >= 16;
+    const float hi = p.xmax[sidx], lo = p.xmin[sidx];
+    float inv_s = 0.f;
+    const QP q = make_qp(hi, lo, lwc, lwc ? p.up[sidx] : 0.f, lwc ? p.low[sidx] : 0.f, p.nbits, p.symmetric, p.inv_q, &inv_s);
+    const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f;
+    float gs = 0.f, nhi = 0.f, nlo = 0.f;
+    for (int64_t i = lane; i < valid; i += 64) {
+        const float x = ld1(w + i), G = ld1(g + i);
+        const float tq = x * inv_s;
+        const float u = (regular ? rintf(tq) : rne_ste(tq)) + q.z;
+        const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
+        const bool in = qv == u;
+        gs = fmaf(G, (qv - q.z) - (in ? tq : 0.f), gs);
+        nhi += x == hi ? 1.f : 0.f;
+        nlo += x == lo ? 1.f : 0.f;
+    }
+    gs = ident ? 0.f : wave_sum(gs);
+    nhi = wave_sum(nhi);
+    nlo = wave_sum(nlo);
+    if (valid < p.seg) {                                     // the padding zeros share the amax / amin gradient
+        if (hi == 0.f) nhi += (float)(p.seg - valid);
+        if (lo == 0.f) nlo += (float)(p.seg - valid);
+    }
+    float ds_dhs, ds_dls;
+    if (p.symmetric) {
+        const float lv = (float)((1 << (p.nbits - 1)) - 1);
+        const float hs = q.su * q.hi, ls = q.sl * q.lo;
+        const float a = fabsf(hs), b = fabsf(ls);
+        const float raw = fmaxf(a, b) / lv;
+        const float pass = (raw >= 1e-5f && raw <= 1e4f) ? 1.f : 0.f;
+        const float sh = hs > 0.f ? 1.f : (hs < 0.f ? -1.f : 0.f);
+        const float sg = ls > 0.f ? 1.f : (ls < 0.f ? -1.f : 0.f);
+        const float wa = a > b ? 1.f : (a == b ? 0.5f : 0.f);
+        ds_dhs = pass * wa * sh / lv;
+        ds_dls = pass * (1.f - wa) * sg / lv;
+    } else {
+        ds_dhs = 1.f / Q;
+        ds_dls = -1.f / Q;
+    }
+    const float g_hs = gs * ds_dhs, g_ls = gs * ds_dls;
+    if (lane == 0) {
+        if (p.g_up) p.g_up[sidx] = g_hs * q.hi * q.su * (1.f - q.su);
+        if (p.g_low) p.g_low[sidx] = g_ls * q.lo * q.sl * (1.f - q.sl);
+    }
+    if (p.gx) {
+        TG* gx = reinterpret_cast<TG*>(p.gx) + r * p.cols + c0;
+        const float tie_hi = g_hs * q.su / nhi, tie_lo = g_ls * q.sl / nlo;
+        for (int64_t i = lane; i < valid; i += 64) {
+            const float x = ld1(w + i), G = ld1(g + i);
+            const float tq = x * inv_s;
+            const float u = (regular ? rintf(tq) : rne_ste(tq)) + q.z;
+            const bool in = ident || __builtin_amdgcn_fmed3f(u, 0.f, Q) == u;
+            float o = in ? G : 0.f;
+            if (!ident) {
+                if (x == hi) o += tie_hi;
+                if (x == lo) o += tie_lo;
+            }
+            st1(gx + i, o);
+        }
+    }
+}
+
+// true when the vector kernels cannot take this segmentation (see check_shape)
+bool needs_generic(int64_t cols, int64_t seg) {
+    if (seg <= 0 || cols <= 0) return false;
+    if (cols % seg != 0 || seg % 8 != 0 || cols > 8 * 512 * 8) return true;
+    if (seg <= 512) { const int64_t l = seg / 8; return (l & (l - 1)) != 0; }
+    return seg != cols;
 }
 
 }  // namespace
@@ -763,6 +913,36 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
                                 int symmetric, const float* col_mul, const float* row_div, const float* row_mul,
                                 const float* shift, const float* up, const float* low, void* y, int y_dtype,
                                 float* scale, float* zp, float* xmin, float* xmax, float* wshift, void* stream) {
+    if (needs_generic(cols, seg)) {
+        OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits <= 16, "oq_fakequant_fwd: bad shape / bitwidth %d", nbits);
+        OQ_CHECK_ARG(w && y && scale && zp && xmin && xmax, "oq_fakequant_fwd: null pointer");
+        OQ_CHECK_ARG((up == nullptr) == (low == nullptr), "oq_fakequant_fwd: up/low must both be given or both NULL");
+        if (col_mul || row_div || row_mul || shift || wshift) {
+            oq_set_error("oq_fakequant_fwd: the LET transform is not available for ragged / non-power-of-two groups "
+                         "(cols %lld, seg %lld)", (long long)cols, (long long)seg);
+            return OQ_E_UNSUPPORTED;
+        }
+        FQ g{};
+        g.w = w; g.rows = rows; g.cols = cols; g.seg = seg; g.nbits = nbits; g.symmetric = symmetric;
+        g.inv_q = 1.0f / (float)((1 << nbits) - 1);
+        g.up = up; g.low = low; g.y = y; g.scale = scale; g.zp = zp; g.xmin = xmin; g.xmax = xmax;
+        const int64_t nsr = (cols + seg - 1) / seg, nseg = rows * nsr;
+        const dim3 grid((unsigned)((nseg + 3) / 4));
+        const int gkey = w_dtype * 3 + y_dtype;
+#define FQ_GEN_FWD(TIN, TOUT) hipLaunchKernelGGL((fq_generic_fwd_kernel<TIN, TOUT>), grid, dim3(256), 0, (hipStream_t)stream, g, nsr)
+        switch (gkey) {
+            case OQ_F32 * 3 + OQ_F32: FQ_GEN_FWD(float, float); break;
+            case OQ_F32 * 3 + OQ_BF16: FQ_GEN_FWD(float, bf16_t); break;
+            case OQ_F16 * 3 + OQ_F32: FQ_GEN_FWD(f16_t, float); break;
+            case OQ_F16 * 3 + OQ_BF16: FQ_GEN_FWD(f16_t, bf16_t); break;
+            case OQ_BF16 * 3 + OQ_BF16: FQ_GEN_FWD(bf16_t, bf16_t); break;
+            default:
+                oq_set_error("oq_fakequant_fwd: unsupported dtype pair in=%d out=%d", w_dtype, y_dtype);
+                return OQ_E_UNSUPPORTED;
+        }
+        OQ_CHECK_LAUNCH("oq_fakequant_fwd(generic)");
+        return OQ_OK;
+    }
     int rc = check_shape("oq_fakequant_fwd", rows, cols, seg, nbits);
     if (rc) return rc;
     OQ_CHECK_ARG(w && y, "oq_fakequant_fwd: null w/y");
@@ -824,6 +1004,38 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
                                 const float* g_wshift, float* g_up, float* g_low, void* gx, int gx_dtype,
                                 float* g_col_mul, float* g_shift, float* g_row_div, float* g_row_mul,
                                 float* workspace, int64_t workspace_floats, void* stream) {
+    if (needs_generic(cols, seg)) {
+        OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits <= 16, "oq_fakequant_bwd: bad shape / bitwidth %d", nbits);
+        OQ_CHECK_ARG(w && g && xmin && xmax, "oq_fakequant_bwd: null pointer");
+        OQ_CHECK_ARG(!gx || gx_dtype == g_dtype, "oq_fakequant_bwd: gx dtype must equal g dtype");
+        OQ_CHECK_ARG((up == nullptr) == (low == nullptr), "oq_fakequant_bwd: up/low must both be given or both NULL");
+        if (col_mul || row_div || row_mul || shift || g_col_mul || g_shift || g_row_div || g_row_mul) {
+            oq_set_error("oq_fakequant_bwd: the LET transform is not available for ragged / non-power-of-two groups "
+                         "(cols %lld, seg %lld)", (long long)cols, (long long)seg);
+            return OQ_E_UNSUPPORTED;
+        }
+        FQ q{};
+        q.w = w; q.rows = rows; q.cols = cols; q.seg = seg; q.nbits = nbits; q.symmetric = symmetric;
+        q.inv_q = 1.0f / (float)((1 << nbits) - 1);
+        q.up = up; q.low = low; q.g = g; q.g_up = g_up; q.g_low = g_low; q.gx = gx;
+        q.xmin = const_cast<float*>(xmin); q.xmax = const_cast<float*>(xmax);
+        const int64_t nsr = (cols + seg - 1) / seg, nseg = rows * nsr;
+        const dim3 grid((unsigned)((nseg + 3) / 4));
+        const int gkey = w_dtype * 3 + g_dtype;
+#define FQ_GEN_BWD(TIN, TG) hipLaunchKernelGGL((fq_generic_bwd_kernel<TIN, TG>), grid, dim3(256), 0, (hipStream_t)stream, q, nsr)
+        switch (gkey) {
+            case OQ_F32 * 3 + OQ_F32: FQ_GEN_BWD(float, float); break;
+            case OQ_F32 * 3 + OQ_BF16: FQ_GEN_BWD(float, bf16_t); break;
+            case OQ_F16 * 3 + OQ_F32: FQ_GEN_BWD(f16_t, float); break;
+            case OQ_F16 * 3 + OQ_BF16: FQ_GEN_BWD(f16_t, bf16_t); break;
+            case OQ_BF16 * 3 + OQ_BF16: FQ_GEN_BWD(bf16_t, bf16_t); break;
+            default:
+                oq_set_error("oq_fakequant_bwd: unsupported dtype pair w=%d g=%d", w_dtype, g_dtype);
+                return OQ_E_UNSUPPORTED;
+        }
+        OQ_CHECK_LAUNCH("oq_fakequant_bwd(generic)");
+        return OQ_OK;
+    }
     int rc = check_shape("oq_fakequant_bwd", rows, cols, seg, nbits);
     if (rc) return rc;
     OQ_CHECK_ARG(w && g, "oq_fakequant_bwd: null w/g");

@@ -64,18 +64,30 @@ class QuantLlamaAttention(nn.Module):
         self.use_act_quant = False
 
     def _rope_tables(self, position_ids, T, device):
-        """cos/sin [T, hd] f32 gathered by position_ids (transformers-4.31 LlamaRotaryEmbedding formula)."""
-        key = (T, str(device), None if position_ids is None else position_ids.data_ptr())
-        if self._rope_cache is not None and self._rope_cache[0] == key:
-            return self._rope_cache[1], self._rope_cache[2]
+        """cos/sin [T, hd] f32 gathered by position_ids (transformers-4.31 LlamaRotaryEmbedding formula; the reference
+        indexes its cos/sin cache with position_ids, models/int_llama_layer.py:124-125).  position_ids: None (= arange),
+        [T] or [bs, T] whose rows are all equal -- per-row positions would need per-sample tables, which the calibration
+        loop never produces; they are rejected instead of silently using row 0.  The cache holds the position_ids tensor
+        itself (identity + version counter), so a new tensor at a recycled address can never hit a stale entry."""
+        c = self._rope_cache
+        if c is not None and c[0] == (T, str(device)) and c[1] is position_ids and \
+                (position_ids is None or c[2] == position_ids._version):
+            return c[3], c[4]
         hd = self.head_dim
         inv = 1.0 / (self.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float32, device=device) / hd))
-        pos = torch.arange(T, dtype=torch.float32, device=device) if position_ids is None else \
-            position_ids.reshape(-1)[:T].to(device=device, dtype=torch.float32)
+        if position_ids is None:
+            pos = torch.arange(T, dtype=torch.float32, device=device)
+        else:
+            pid = position_ids.reshape(-1, position_ids.shape[-1])
+            if pid.shape[-1] != T:
+                raise ValueError(f"position_ids of length {pid.shape[-1]} for a sequence of length {T}")
+            if pid.shape[0] > 1 and not bool((pid == pid[:1]).all()):
+                raise NotImplementedError("per-sample position_ids (rows differ) are not supported on the HIP path")
+            pos = pid[0].to(device=device, dtype=torch.float32)
         fr = torch.outer(pos, inv)
         emb = torch.cat((fr, fr), dim=-1)
         cos, sin = emb.cos().contiguous(), emb.sin().contiguous()
-        self._rope_cache = (key, cos, sin)
+        self._rope_cache = ((T, str(device)), position_ids, None if position_ids is None else position_ids._version, cos, sin)
         return cos, sin
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
@@ -98,7 +110,7 @@ class QuantLlamaAttention(nn.Module):
             if attention_mask.size() != (bsz, 1, q_len, q_len):
                 raise ValueError(f"Attention mask should be of size {(bsz, 1, q_len, q_len)}, but is "
                                  f"{attention_mask.size()}")
-            mask = attention_mask[0, 0]
+            mask = attention_mask            # [bs,1,T,T]: every sample keeps its own mask (ops.SoftmaxFn)
         causal = ops.mask_is_causal(attention_mask)   # exact causal mask -> the masked half is skipped everywhere
         pq = self.pv_matmul.x1_quantizer
         p_identity = (not self.pv_matmul.use_act_quant) or pq.n_bits >= 16 or not pq.enable
@@ -142,6 +154,7 @@ class QuantLlamaDecoderLayer(QuantBlockMixin, nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
                 output_attentions=False, use_cache=False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        hidden_states, back = self._enter(hidden_states)
         residual = hidden_states
         h = self.input_layernorm(hidden_states)
         # the two residual adds (models/int_llama_layer.py:246,264) are folded into the o_proj / down_proj GEMM stores
@@ -150,4 +163,4 @@ class QuantLlamaDecoderLayer(QuantBlockMixin, nn.Module):
                                              use_cache=use_cache, residual=residual)
         h, res = self.post_attention_layernorm.forward_with_residual(hidden_states)   # residual-path grad joins in norm bwd
         hidden_states = self.mlp(h, residual=res)
-        return (hidden_states,)
+        return (self._leave(hidden_states, back),)

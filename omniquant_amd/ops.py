@@ -39,7 +39,7 @@ class FakeQuantFn(torch.autograd.Function):
         w = w.contiguous()
         cols = w.shape[-1]
         rows = w.numel() // cols
-        nseg = rows * (cols // seg)
+        nseg = rows * ((cols + seg - 1) // seg)          # a ragged last segment is zero-padded inside the kernel
         y = torch.empty(w.shape, dtype=out_dtype, device=w.device)
         scale = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
         zp = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
@@ -76,7 +76,7 @@ class FakeQuantFn(torch.autograd.Function):
         if gy is None:
             gy = torch.zeros(w.shape, dtype=torch.float32, device=dev)
         gy = gy.contiguous()
-        nseg = rows * (cols // seg)
+        nseg = rows * ((cols + seg - 1) // seg)
         r_cm, r_rd, r_rm, r_sh, r_up, r_low = ctx.route
         g_up = (r_up._oq_grad_sink.view(nseg, 1) if r_up is not None else
                 torch.empty((nseg, 1), dtype=torch.float32, device=dev)) if need[5] else None
@@ -483,7 +483,10 @@ class ReluFn(torch.autograd.Function):
 
 
 class SoftmaxFn(torch.autograd.Function):
-    """p = softmax(max(s*alpha + mask, finfo.min)) in f32 (models/int_llama_layer.py:143-160)."""
+    """p = softmax(max(s*alpha + mask, finfo.min)) in f32 (models/int_llama_layer.py:143-160).
+
+    s [bs, nh, T, Tk].  mask: None, one [T, Tk] mask shared by every sample and head, or the reference's
+    [bs, 1, T, Tk] additive mask -- each sample then gets ITS mask (one launch per sample when they differ)."""
 
     @staticmethod
     def forward(ctx, s, mask, alpha, causal=False):
@@ -491,13 +494,35 @@ class SoftmaxFn(torch.autograd.Function):
         cols = s.shape[-1]
         rows = s.numel() // cols
         p = torch.empty_like(s)
-        m32, mrows = None, 0
         causal = bool(causal) and s.shape[-2] == cols
+        per_sample = None
+        m32, mrows = None, 0
         if mask is not None and not causal:
-            m32 = mask.detach().float().contiguous().view(-1, cols)
-            mrows = m32.shape[0]
-        C.call("oq_softmax_fwd", C.ptr(s), C.ptr(p), C.dt(s), rows, cols, float(alpha), C.fptr(m32), mrows, int(causal),
-               C.stream())
+            m = mask.detach()
+            if m.dim() == 4:
+                if m.shape[1] != 1 or tuple(m.shape[-2:]) != tuple(s.shape[-2:]):
+                    raise C.OQError(f"SoftmaxFn: mask {tuple(m.shape)} does not fit scores {tuple(s.shape)}")
+                if m.shape[0] == 1 or m.stride(0) == 0:
+                    m = m[0, 0]                                      # one mask broadcast over the batch
+                elif s.dim() != 4 or m.shape[0] != s.shape[0]:
+                    raise C.OQError(f"SoftmaxFn: mask batch {m.shape[0]} != scores batch {tuple(s.shape)}")
+                else:
+                    per_sample = m[:, 0].float().contiguous()         # [bs, T, Tk]
+            if per_sample is None:
+                if m.dim() != 2 or m.shape[-1] != cols:
+                    raise C.OQError(f"SoftmaxFn: mask {tuple(m.shape)} does not fit scores {tuple(s.shape)}")
+                m32 = m.float().contiguous().view(-1, cols)
+                mrows = m32.shape[0]
+        if per_sample is not None:
+            bs = s.shape[0]
+            rps = rows // bs
+            es = s.element_size()
+            for b in range(bs):
+                C.call("oq_softmax_fwd", s.data_ptr() + b * rps * cols * es, p.data_ptr() + b * rps * cols * es, C.dt(s),
+                       rps, cols, float(alpha), C.fptr(per_sample[b]), per_sample.shape[1], 0, C.stream())
+        else:
+            C.call("oq_softmax_fwd", C.ptr(s), C.ptr(p), C.dt(s), rows, cols, float(alpha), C.fptr(m32), mrows,
+                   int(causal), C.stream())
         ctx.save_for_backward(p)
         ctx.alpha = float(alpha)
         ctx.causal = causal
@@ -637,6 +662,12 @@ class LetVectorsFn(torch.autograd.Function):
         n = s1.numel()
         ins = [x.detach().contiguous() if x is not None else None
                for x in (s1, h1, s2, h2, s3, h3, t, ln1_w, ln1_b, ln2_w, ln2_b, ws_q, ws_k, ws_v, ws_o, bq0, bk0, bv0, bo0)]
+        for x in ins:
+            # the kernel reads n elements of every vector: a shorter one (GQA k/v projections with LET, which the
+            # reference rejects with a broadcast error, models/transformation.py:63-69) must not get that far
+            if x is not None and x.numel() != n:
+                raise NotImplementedError(f"LET vector of {x.numel()} elements in a block of hidden size {n}: LET needs "
+                                          "equal q/k/v output widths (no grouped-query attention)")
         outs = [torch.empty(n, dtype=torch.float32, device=s1.device) for _ in range(8)]
         C.call("oq_let_vectors_fwd", n, *[C.fptr(x) for x in ins], *[C.fptr(o) for o in outs], C.stream())
         ctx.save_for_backward(*[x for x in ins if x is not None])
@@ -664,8 +695,10 @@ class LetVectorsFn(torch.autograd.Function):
 
 
 def mask_is_causal(attention_mask):
-    """True iff the additive attention mask ([T,T] or [bs,1,T,T]) is exactly the causal one (0 on/below the
-    diagonal, <= -1e30 above it, so masked probabilities are exactly 0).  The check costs one host sync, so its
+    """True iff the additive attention mask ([T,T] or [bs,1,T,T]) is exactly the causal one: 0 on/below the diagonal
+    and <= -3e4 above it -- finfo(float32).min, or finfo(float16).min = -65504 as transformers builds it for the fp16
+    model the reference hands to its Catcher (quantize/omniquant.py:89-113); either way exp(masked - row max) is exactly
+    0 in float32, so masked probabilities are exactly 0 on both paths.  The check costs one host sync, so its
     result is cached ON the tensor object (or on the base tensor of an expand()/index view) together with the
     tensor's version counter; the causal fast path then skips the masked half of every attention GEMM and of the
     softmax."""
@@ -677,14 +710,15 @@ def mask_is_causal(attention_mask):
     if Tm >= 256 and Tm % 256 != 0:                  # the causal GEMM modes contract in 256-blocks: dense path instead
         return False
     root = attention_mask._base if attention_mask._base is not None else attention_mask
-    tag = (root._version, tuple(attention_mask.shape))
+    # (a view is identified by its window into the base tensor: two slices of one batched mask must not share a verdict)
+    tag = (root._version, tuple(attention_mask.shape), tuple(attention_mask.stride()), attention_mask.storage_offset())
     cached = getattr(root, "_oq_causal", None)
     if cached is not None and cached[0] == tag:
         return cached[1]
     T = attention_mask.shape[-1]
     m = attention_mask.reshape(-1, T, T).float()
     lower = torch.tril(torch.ones(T, T, dtype=torch.bool, device=m.device))
-    hit = bool(T > 1 and ((m == 0) == lower).all().item() and (m[:, ~lower] <= -1e30).all().item())
+    hit = bool(T > 1 and ((m == 0) == lower).all().item() and (m[:, ~lower] <= -3e4).all().item())
     try:
         root._oq_causal = (tag, hit)
     except Exception:

@@ -54,7 +54,7 @@ class QuantOPTAttention(nn.Module):
             if attention_mask.size() != (bsz, 1, tgt_len, tgt_len):
                 raise ValueError(f"Attention mask should be of size {(bsz, 1, tgt_len, tgt_len)}, but is "
                                  f"{attention_mask.size()}")
-            mask = attention_mask[0, 0]
+            mask = attention_mask            # [bs,1,T,T]: every sample keeps its own mask (ops.SoftmaxFn)
         causal = ops.mask_is_causal(attention_mask)
         scores = self.qkt_matmul.scores(q, k, causal)
         probs = ops.SoftmaxFn.apply(scores, mask, 1.0, causal)
@@ -96,6 +96,7 @@ class QuantOPTDecoderLayer(QuantBlockMixin, nn.Module):
                 use_cache=False, past_key_value=None, **kwargs) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         if use_cache or output_attentions:
             raise NotImplementedError("the calibration hot path runs without KV cache / attention outputs")
+        hidden_states, back = self._enter(hidden_states)
         residual = hidden_states
         h = self.self_attn_layer_norm(hidden_states) if self.do_layer_norm_before else hidden_states
         hidden_states, _, _ = self.self_attn(hidden_states=h, past_key_value=past_key_value, attention_mask=attention_mask,
@@ -110,4 +111,4 @@ class QuantOPTDecoderLayer(QuantBlockMixin, nn.Module):
         hidden_states = self.fc2(ops.ReluFn.apply(self.fc1(h)), residual=residual)
         if not self.do_layer_norm_before:
             hidden_states = self.final_layer_norm(hidden_states)
-        return (hidden_states,)
+        return (self._leave(hidden_states, back),)

@@ -7,7 +7,8 @@ i's student input is block i-1's trained output.  The sharding implemented here 
   1. rank r owns the contiguous chunk  layers[lo(r):hi(r)];
   2. teacher pre-pass, pipelined: rank r receives the FP activation bank at its chunk boundary from rank r-1
      (point-to-point send/recv -- on MI355X one xGMI link, 2.15 GB at LLaMA-7B), forwards it through its own chunk
-     with quantisation off and sends the result to rank r+1;
+     with quantisation off and sends the result to rank r+1 -- streamed in messages of a few samples with the next
+     receive and the previous send in flight under the compute, so all ranks work on the pre-pass at once;
   3. every rank calibrates its chunk exactly like the single-GPU engine, except that the student input of its FIRST
      block is the teacher activation (G-1 boundaries deviate from the reference);
   4. learned parameters are gathered on rank 0 (gather_object of small fp16 dicts).
@@ -29,21 +30,43 @@ def shard_bounds(n_layers, world, rank):
     return lo, hi
 
 
-def pipeline_teacher_boundaries(inps, lo, hi, teacher_chunk_forward, group=None):
-    """Step 2.  `teacher_chunk_forward(lo, hi, bank) -> bank` runs layers [lo, hi) with quantisation off.
-    Returns the FP activation bank at THIS rank's chunk input (rank 0: `inps` itself)."""
+def pipeline_teacher_boundaries(inps, lo, hi, teacher_chunk_forward, group=None, chunk=None):
+    """Step 2.  `teacher_chunk_forward(lo, hi, bank) -> bank` runs layers [lo, hi) with quantisation off on ANY number
+    of samples.  Returns the FP activation bank at THIS rank's chunk input (rank 0: `inps` itself).
+
+    The bank is streamed in messages of `chunk` samples (None: one message, store-and-forward): rank r forwards message
+    c through its layers and isend()s the result while it already computes message c+1, and it posts the irecv() of
+    message c+1 before computing c -- so rank r+1 starts after ONE message has crossed r's layers, not the whole bank,
+    and the last of G ranks starts after G-1 message latencies instead of G-1 bank passes.  Only point-to-point
+    send/recv (RCCL over one xGMI link per boundary); message order per (src, dst) pair is FIFO in both backends."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = inps.shape[0]
+    step = n if not chunk or chunk <= 0 else min(int(chunk), n)
     # RCCL ("nccl") moves device buffers directly over xGMI; gloo (CPU tests, or ranks sharing one GPU) has no
-    # device point-to-point, so the bank is staged through host memory there
+    # device point-to-point, so messages are staged through host memory there
     staged = inps.is_cuda and dist.get_backend(group) == "gloo"
+    comm_dev = "cpu" if staged else inps.device
+    bounds = [(a, min(a + step, n)) for a in range(0, n, step)]
     bank = inps
+    recv_req = None
     if rank > 0:
-        buf = torch.empty(inps.shape, dtype=inps.dtype, device="cpu" if staged else inps.device)
-        dist.recv(buf, src=rank - 1, group=group)
-        bank = buf.to(inps.device) if staged else buf
-    if rank < world - 1:
-        out = teacher_chunk_forward(lo, hi, bank.clone()).contiguous()
-        dist.send(out.cpu() if staged else out, dst=rank + 1, group=group)
+        bank = torch.empty(inps.shape, dtype=inps.dtype, device=inps.device)
+        rbuf = [torch.empty((b - a,) + tuple(inps.shape[1:]), dtype=inps.dtype, device=comm_dev) for a, b in bounds]
+        recv_req = dist.irecv(rbuf[0], src=rank - 1, group=group)
+    pending = []
+    for c, (a, b) in enumerate(bounds):
+        if rank > 0:
+            recv_req.wait()
+            if c + 1 < len(bounds):
+                recv_req = dist.irecv(rbuf[c + 1], src=rank - 1, group=group)     # next message lands under this compute
+            bank[a:b].copy_(rbuf[c])
+            rbuf[c] = None
+        if rank < world - 1:
+            out = teacher_chunk_forward(lo, hi, bank[a:b].clone()).contiguous()
+            msg = out.cpu() if staged else out
+            pending.append((dist.isend(msg, dst=rank + 1, group=group), msg))       # keep the buffer alive until sent
+    for req, _ in pending:
+        req.wait()
     return bank
 
 
@@ -63,12 +86,13 @@ def gather_omni_parameters(local, group=None):
     return dict(sorted(merged.items()))
 
 
-def calibrate_sharded(n_layers, inps, teacher_chunk_forward, calibrate_chunk, group=None):
+def calibrate_sharded(n_layers, inps, teacher_chunk_forward, calibrate_chunk, group=None, chunk=None):
     """Full protocol.  `calibrate_chunk(lo, hi, teacher_bank, student_bank) -> {layer_idx: omni dict}`.
+    `chunk`: samples per boundary message of the teacher pre-pass (None: the whole bank in one message).
     Returns (merged omni parameters on rank 0 / None elsewhere, (lo, hi))."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lo, hi = shard_bounds(n_layers, world, rank)
-    bank = pipeline_teacher_boundaries(inps, lo, hi, teacher_chunk_forward, group)
+    bank = pipeline_teacher_boundaries(inps, lo, hi, teacher_chunk_forward, group, chunk)
     local = calibrate_chunk(lo, hi, bank, bank.clone()) if hi > lo else {}
     merged = gather_omni_parameters(local, group)
     return merged, (lo, hi)
@@ -82,14 +106,19 @@ def hip_callables(layers, config, args, attention_mask, position_ids, act_scales
     family = family_of(args.net)
     is_llama = family == "llama"
 
+    teachers = {}           # layer index -> FP block, built once (the pre-pass calls this once per streamed message)
+    mask32 = attention_mask.float().contiguous() if attention_mask is not None else None
+
     def teacher_chunk_forward(lo, hi, bank):
         bank = bank.to(compute_dtype)
-        mask = attention_mask.float().contiguous()
         for i in range(lo, hi):
-            q = decoder_layer_class(family)(config, layers[i], args).to(bank.device)
-            q.compute_dtype = compute_dtype
-            q.set_quant_state(weight_quant=False, act_quant=False)
-            forward_bank(q, bank, bank, mask, position_ids, is_llama)
+            q = teachers.get(i)
+            if q is None:
+                q = decoder_layer_class(family)(config, layers[i], args).to(bank.device)
+                q.compute_dtype = compute_dtype
+                q.set_quant_state(weight_quant=False, act_quant=False)
+                teachers[i] = q
+            forward_bank(q, bank, bank, mask32, position_ids, is_llama)
         return bank
 
     def calibrate_chunk(lo, hi, teacher_bank, student_bank):

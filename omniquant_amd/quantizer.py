@@ -62,19 +62,35 @@ class UniformAffineQuantizer(nn.Module):
     def _segment(self, x):
         if self.group_size:
             assert len(x.shape) == 2, "only support linear layer now"
-            if self.deficiency > 0:
-                raise NotImplementedError("ragged weight groups (in_features % group_size != 0) are not "
-                                          "implemented on the HIP path")
             return self.group_size
         return x.shape[-1]
 
+    def _identity(self):
+        return self.n_bits >= 16 or not self.enable
+
     def quantize(self, x, out_dtype=None, col_mul=None, row_div=None, row_mul=None, shift=None):
         """Dynamic calibration + fake quant in ONE kernel, optionally fused with the LET weight transform
-        x' = ((x*col_mul)/row_div)*row_mul and the by-product x @ shift.  Sets self.scale/round_zero_point."""
+        x' = ((x*col_mul)/row_div)*row_mul and the by-product x @ shift.  Sets self.scale/round_zero_point.
+
+        n_bits >= 16 or a disabled quantizer is the identity of the reference's forward() gate
+        (quantize/quantizer.py:109-110): the tensor comes back unchanged (cast to out_dtype), scale / zero-point stay
+        None; with LET arguments the transform still runs (kernel's identity grid).
+        A ragged last group (in_features % group_size != 0, symmetric only as in the reference, :64-69) is zero-padded
+        inside the kernel exactly like :85-87 / :125-128."""
+        let = not (col_mul is None and row_div is None and row_mul is None and shift is None)
+        if self._identity():
+            self.scale = self.round_zero_point = None
+            if not let:
+                return ops.cast(x, out_dtype) if out_dtype is not None else x
+            res = ops.fake_quant(x, 16, x.shape[-1], None, None, False, out_dtype, None, col_mul, row_div, row_mul, shift)
+            return res
         stash = {}
         up = self.upbound_factor if self.lwc else None
         low = self.lowbound_factor if self.lwc else None
-        res = ops.fake_quant(x, self.n_bits, self._segment(x), up, low, self.symmetric, out_dtype, stash,
+        seg = self._segment(x)
+        if self.group_size and x.shape[-1] % seg != 0:
+            assert self.symmetric, "ragged weight groups are only defined for the symmetric grid (quantizer.py:69)"
+        res = ops.fake_quant(x, self.n_bits, seg, up, low, self.symmetric, out_dtype, stash,
                              col_mul, row_div, row_mul, shift)
         self.scale, self.round_zero_point = stash["scale"], stash["zp"]
         return res
@@ -93,7 +109,30 @@ class UniformAffineQuantizer(nn.Module):
         self.quantize(x.detach())
 
     def fake_quant(self, x, scale=None, round_zero_point=None):
-        return self.quantize(x)
+        """API parity with quantize/quantizer.py:84-105.  Called with this quantizer's own freshly calibrated
+        scale / zero-point (the only way the reference calls it) it is the fused kernel; explicit foreign parameters are
+        applied with the reference's formula on the device (not on the calibration path)."""
+        if scale is None or (scale is self.scale and round_zero_point is self.round_zero_point):
+            return self.quantize(x)
+        shape = x.shape
+        xg = x
+        if self.group_size:
+            assert len(shape) == 2, "only support linear layer now"
+            if self.deficiency > 0:
+                xg = torch.cat((x, x.new_zeros(shape[0], self.deficiency)), dim=1)
+            xg = xg.reshape(-1, self.group_size)
+        x_int = round_ste(xg / scale)
+        if round_zero_point is not None:
+            x_int = x_int.add(round_zero_point)
+        x_int = x_int.clamp(self.qmin, self.qmax)
+        if round_zero_point is not None:
+            x_int = x_int.sub(round_zero_point)
+        y = x_int.mul(scale)
+        if self.group_size:
+            y = y.reshape(shape[0], -1)
+            if self.deficiency > 0:
+                y = y[:, :-self.deficiency]
+        return y
 
     def register_scales_and_zeros(self):
         self.register_buffer("scales", self.scale)

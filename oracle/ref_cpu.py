@@ -9,6 +9,11 @@ Parity status: PINNED.  Every function here is checked against golden vectors pr
 importing the reference itself in the build container (tests/golden/gen_golden.py ->
 tests/golden/*.npz; tests/test_oracle_vs_golden.py).
 
+Besides the pinned fp32 arithmetic, `Block.forward(act_dtype=...)` / `Block.temporaries(store_dtype=...)` can round
+every tensor the product path materialises in bf16 (value and gradient) while keeping fp32 arithmetic: a CPU model of
+the bf16 production mode, used only by tests/test_fullsize_parity.py to separate "precision mode" from "kernel bug".
+The default (None) is the reference's arithmetic and the only mode the golden vectors pin.
+
 Reference lines restated (all under /root/reference):
   fake_quant_*            quantize/quantizer.py:15-19 (round_ste), :84-105 (fake_quant),
                           :122-147 (per_token_dynamic_calibration)
@@ -118,6 +123,77 @@ def let_init_scale(act_absmax, weight, alpha):
     a = act_absmax.clamp(min=1e-5)
     w = weight.max(dim=0)[0].clamp(min=1e-5)           # signed column max (quirk Q4)
     return (a.pow(alpha) / w.pow(1 - alpha)).clamp(min=1e-5)
+
+
+# ----------------------------------------------------------------------------------------------
+# precision-mode emulation (NOT part of the reference algorithm)
+# ----------------------------------------------------------------------------------------------
+class _RoundSTE(torch.autograd.Function):
+    """Value and gradient rounded to `dtype` and back: stands for a tensor that is MATERIALISED in that dtype between
+    two kernels (the product path's bf16 production mode), while all arithmetic stays fp32 as in the kernels."""
+
+    @staticmethod
+    def forward(ctx, t, dtype):
+        ctx.dtype = dtype
+        return t.to(dtype).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+class _GradRoundSTE(torch.autograd.Function):
+    """Identity forward, gradient rounded to `dtype`: a tensor whose GRADIENT is materialised in that dtype."""
+
+    @staticmethod
+    def forward(ctx, t, dtype):
+        ctx.dtype = dtype
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+class _FusedAttnModel(torch.autograd.Function):
+    """Storage model of the product path's fused causal attention (omniquant_amd/csrc/oq_attn.hip), fp32 arithmetic:
+    forward  P = softmax(scale * q k^T + mask) in fp32, rounded to `dtype` only as the operand of P @ v;
+    backward as the kernel does it: dV = P_r^T dO, dP = dO v^T, D = rowsum(dO * O_r) with the STORED (rounded) output,
+    dS = P * (dP - D) rounded to `dtype` (the kernel stores dS^T in bf16), dQ = scale * dS k, dK = scale * dS^T q.
+    The mathematics is that of models/int_llama_layer.py:143-163; only the rounding points are the kernel's."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale, dtype):
+        s = torch.matmul(q, k.transpose(2, 3)) * scale
+        if mask is not None:
+            s = torch.max(s + mask, torch.tensor(torch.finfo(s.dtype).min))
+        p = torch.softmax(s, dim=-1)
+        pr = p.to(dtype).to(p.dtype)
+        o = torch.matmul(pr, v)
+        orr = o.to(dtype).to(o.dtype)
+        ctx.save_for_backward(q, k, v, p, pr, orr)
+        ctx.scale, ctx.dtype = scale, dtype
+        return orr
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, p, pr, orr = ctx.saved_tensors
+        dt = ctx.dtype
+        go = go.to(dt).to(go.dtype)
+        dv = torch.matmul(pr.transpose(2, 3), go)
+        dp = torch.matmul(go, v.transpose(2, 3))
+        d = (go * orr).sum(-1, keepdim=True)
+        ds = (p * (dp - d)).to(dt).to(p.dtype)
+        dq = torch.matmul(ds, k) * ctx.scale
+        dk = torch.matmul(ds.transpose(2, 3), q) * ctx.scale
+        return dq, dk, dv, None, None, None
+
+
+def _rounder(dtype):
+    """None -> identity (the reference's pure-fp32 CPU arithmetic, the pinned mode)."""
+    if dtype is None:
+        return lambda t: t
+    return lambda t: _RoundSTE.apply(t, dtype)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -285,9 +361,12 @@ class Block:
         self.qparams[name] = (sc, zp)
         return y
 
-    def temporaries(self):
-        """Returns dict of temp tensors: '<linear>.weight', '<linear>.bias', '<ln>.weight', '<ln>.bias'."""
+    def temporaries(self, store_dtype=None):
+        """Returns dict of temp tensors: '<linear>.weight', '<linear>.bias', '<ln>.weight', '<ln>.bias'.
+        store_dtype (precision-mode emulation only): the fake-quantised weights are rounded to that dtype, as the
+        product path stores them for its bf16 MFMA GEMMs; biases and norm parameters stay fp32 there too."""
         nm, P, W = self.names, self.params, self.w
+        rw = _rounder(store_dtype)
         t = {}
         if self.spec.let:
             with torch.no_grad():
@@ -321,7 +400,7 @@ class Block:
             for n in self.order:
                 t[n + ".weight"] = W[n + ".weight"]
         for n in self.order:
-            t[n + ".weight"] = self._wq(n, t[n + ".weight"])
+            t[n + ".weight"] = rw(self._wq(n, t[n + ".weight"]))
             if n + ".bias" not in t:
                 t[n + ".bias"] = self._bias(n)
         return t
@@ -339,64 +418,85 @@ class Block:
             return (w * xh + b).to(x.dtype) if b is not None else (w * xh).to(x.dtype)
         return F.layer_norm(x, (self.H,), w, b, eps=self.eps)
 
-    def _lin(self, x, name, t, act_quant):
+    def _lin(self, x, name, t, act_quant, rnd=None, residual=None):
         w = t[name + ".weight"] if t else self.w[name + ".weight"]
         b = t[name + ".bias"] if t else self.w.get(name + ".bias")
-        return F.linear(self._aq(x, act_quant), w, b)
+        xin = self._aq(x, act_quant)
+        if rnd is not None and act_quant and self.spec.abits < 16:
+            xin = rnd(xin)                                  # the quantised activation is stored before the GEMM
+        y = F.linear(xin, w, b)
+        if residual is not None:
+            y = residual + y                                # (the product path adds the residual in the GEMM's store)
+        return rnd(y) if rnd is not None else y
 
-    def forward(self, x, mask=None, position_ids=None, temps=None, act_quant=True):
-        """x [bs,T,H].  temps=None -> raw (or folded) weights; act_quant toggles every activation quantizer."""
+    def forward(self, x, mask=None, position_ids=None, temps=None, act_quant=True, act_dtype=None):
+        """x [bs,T,H].  temps=None -> raw (or folded) weights; act_quant toggles every activation quantizer.
+        act_dtype (precision-mode emulation only, default None = the reference's fp32 arithmetic): every activation the
+        product path materialises between two kernels is rounded to that dtype (value and gradient), arithmetic stays
+        fp32 -- the CPU model of the bf16 production mode."""
         nm = self.names
         bs, T, H = x.shape
-        h = self._norm(x, nm["ln1"], temps)
+        R_ = _rounder(act_dtype)
+        rnd = R_ if act_dtype is not None else None
+        aq4 = act_quant and self.spec.abits < 16
+        h = R_(self._norm(x, nm["ln1"], temps))
         if self.family == "llama":
-            q = self._lin(h, nm["q"], temps, act_quant).view(bs, T, self.nh, self.hd).transpose(1, 2)
-            k = self._lin(h, nm["k"], temps, act_quant).view(bs, T, self.nkv, self.hd).transpose(1, 2)
-            v = self._lin(h, nm["v"], temps, act_quant).view(bs, T, self.nkv, self.hd).transpose(1, 2)
+            q = self._lin(h, nm["q"], temps, act_quant, rnd).view(bs, T, self.nh, self.hd).transpose(1, 2)
+            k = self._lin(h, nm["k"], temps, act_quant, rnd).view(bs, T, self.nkv, self.hd).transpose(1, 2)
+            v = self._lin(h, nm["v"], temps, act_quant, rnd).view(bs, T, self.nkv, self.hd).transpose(1, 2)
             cos = self.cos[:T][position_ids].unsqueeze(1)
             sin = self.sin[:T][position_ids].unsqueeze(1)
-            q = q * cos + _rot_half(q) * sin
-            k = k * cos + _rot_half(k) * sin
+            q = R_(q * cos + _rot_half(q) * sin)
+            k = R_(k * cos + _rot_half(k) * sin)
             rep = self.nh // self.nkv
             if rep > 1:
                 k = k[:, :, None].expand(bs, self.nkv, rep, T, self.hd).reshape(bs, self.nh, T, self.hd)
                 v = v[:, :, None].expand(bs, self.nkv, rep, T, self.hd).reshape(bs, self.nh, T, self.hd)
             q, k = self._aq(q, act_quant), self._aq(k, act_quant)
-            att = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(self.hd)
-            if mask is not None:
-                att = att + mask
-                att = torch.max(att, torch.tensor(torch.finfo(att.dtype).min))
-            att = F.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
+            if aq4:
+                q, k = R_(q), R_(k)
             v = self._aq(v, act_quant)
-            o = torch.matmul(att, v).transpose(1, 2).reshape(bs, T, H)
-            o = self._lin(o, nm["o"], temps, act_quant)
-            h = x + o
-            h2 = self._norm(h, nm["ln2"], temps)
-            gate = self._lin(h2, "mlp.gate_proj", temps, act_quant)
-            up = self._lin(h2, "mlp.up_proj", temps, act_quant)
-            d = self._lin(F.silu(gate) * up, "mlp.down_proj", temps, act_quant)
-            return h + d
+            if aq4:
+                v = R_(v)
+            if act_dtype is not None and self.hd == 128:
+                # the product path's fused kernels (bf16, head_dim 128, causal): their own rounding points
+                o = _FusedAttnModel.apply(q, k, v, mask, 1.0 / math.sqrt(self.hd), act_dtype)
+                o = o.transpose(1, 2).reshape(bs, T, H)
+            else:
+                att = R_(torch.matmul(q, k.transpose(2, 3))) / math.sqrt(self.hd) if act_dtype is not None else \
+                    torch.matmul(q, k.transpose(2, 3)) / math.sqrt(self.hd)
+                if mask is not None:
+                    att = att + mask
+                    att = torch.max(att, torch.tensor(torch.finfo(att.dtype).min))
+                att = F.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
+                o = R_(torch.matmul(R_(att), v).transpose(1, 2).reshape(bs, T, H))
+            h = self._lin(o, nm["o"], temps, act_quant, rnd, residual=x)
+            h2 = R_(self._norm(h, nm["ln2"], temps))
+            gate = self._lin(h2, "mlp.gate_proj", temps, act_quant, rnd)
+            up = self._lin(h2, "mlp.up_proj", temps, act_quant, rnd)
+            return self._lin(R_(F.silu(gate) * up), "mlp.down_proj", temps, act_quant, rnd, residual=h)
         # ---- OPT: q/k/v are quantised per token over the full hidden dim before the head split
         scaling = self.hd ** -0.5
-        q = self._aq(self._lin(h, nm["q"], temps, act_quant) * scaling, act_quant)
-        k = self._aq(self._lin(h, nm["k"], temps, act_quant), act_quant)
-        v = self._aq(self._lin(h, nm["v"], temps, act_quant), act_quant)
+        q = self._aq(R_(self._lin(h, nm["q"], temps, act_quant, rnd) * scaling), act_quant)
+        k = self._aq(self._lin(h, nm["k"], temps, act_quant, rnd), act_quant)
+        v = self._aq(self._lin(h, nm["v"], temps, act_quant, rnd), act_quant)
+        if aq4:
+            q, k, v = R_(q), R_(k), R_(v)
 
         def split(t_):
             return t_.view(bs, T, self.nh, self.hd).transpose(1, 2).contiguous().view(bs * self.nh, T, self.hd)
         q, k, v = split(q), split(k), split(v)
-        att = torch.bmm(q, k.transpose(1, 2))
+        att = R_(torch.bmm(q, k.transpose(1, 2)))
         if mask is not None:
             att = att.view(bs, self.nh, T, T) + mask
             att = torch.max(att, torch.tensor(torch.finfo(att.dtype).min)).view(bs * self.nh, T, T)
-        att = F.softmax(att, dim=-1)
-        o = torch.bmm(att, v).view(bs, self.nh, T, self.hd).transpose(1, 2).reshape(bs, T, H)
-        o = self._lin(o, nm["o"], temps, act_quant)
-        h = (x + o).reshape(-1, H)
-        h2 = self._norm(h, nm["ln2"], temps)
-        f = F.relu(self._lin(h2, "fc1", temps, act_quant))
-        f = self._lin(f, "fc2", temps, act_quant)
-        return (h + f).view(bs, T, H)
+        att = R_(F.softmax(att, dim=-1))
+        o = R_(torch.bmm(att, v).view(bs, self.nh, T, self.hd).transpose(1, 2).reshape(bs, T, H))
+        h = self._lin(o, nm["o"], temps, act_quant, rnd, residual=x).reshape(-1, H)
+        h2 = R_(self._norm(h, nm["ln2"], temps))
+        f = R_(F.relu(self._lin(h2, "fc1", temps, act_quant, rnd)))
+        f = self._lin(f, "fc2", temps, act_quant, rnd, residual=h)
+        return f.view(bs, T, H)
 
     # ---- final fold --------------------------------------------------------------------------
     @torch.no_grad()

@@ -17,7 +17,7 @@ Generator-side shims (written here, not reference code):
     the reference block (models/int_llama_layer.py:70,124-125) expects the 4.31-era API.
     `_OldRotary` + `_old_apply_rotary` restate that published formula.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py [act_stats | round2]
 """
 import json
 import os
@@ -313,9 +313,10 @@ def fwd(qlayer, x, mask, pos, is_llama):
 # --------------------------------------------------------------------------------------
 # G2 + G3: LET temporaries and one full block step (fwd, loss, every grad)
 # --------------------------------------------------------------------------------------
-def gen_block_step(is_llama, tag, wbits, abits, group, lwc, let, T=16, randomize=True):
+def gen_block_step(is_llama, tag, wbits, abits, group, lwc, let, T=16, randomize=True, cfg_over=None, save_tmp=True):
     fam = "llama" if is_llama else "opt"
-    cfg = LlamaConfig(**LLAMA_TINY) if is_llama else OPTConfig(**OPT_TINY)
+    cfg_dict = dict(LLAMA_TINY if is_llama else OPT_TINY, **(cfg_over or {}))
+    cfg = LlamaConfig(**cfg_dict) if is_llama else OPTConfig(**cfg_dict)
     prefix = "model.layers" if is_llama else "model.decoder.layers"
     g = torch.Generator().manual_seed(11)
     layer = llama_layer(cfg, 3) if is_llama else opt_layer(cfg, 3)
@@ -357,8 +358,10 @@ def gen_block_step(is_llama, tag, wbits, abits, group, lwc, let, T=16, randomize
     arrays.update(x=np32(x), target=np32(target), mask=np32(mask), position_ids=pos.numpy())
 
     qlayer.smooth_and_quant_temporary()
-    # G2: temporaries
+    # G2: temporaries (left out of the larger fixtures: they would dominate the file)
     for n, m in qlayer.named_modules():
+        if not save_tmp:
+            break
         if hasattr(m, "temp_weight") and m.temp_weight is not None:
             arrays["tmp." + n + ".temp_weight"] = np32(m.temp_weight)
         if hasattr(m, "temp_bias") and getattr(m, "temp_bias") is not None:
@@ -381,7 +384,7 @@ def gen_block_step(is_llama, tag, wbits, abits, group, lwc, let, T=16, randomize
     with torch.no_grad():
         arrays["out_fp"] = np32(fwd(qlayer, x, mask, pos, is_llama))
     meta = dict(family=fam, wbits=wbits, abits=abits, group_size=group, lwc=lwc, let=let, T=T,
-                config=LLAMA_TINY if is_llama else OPT_TINY, alpha=0.5, layer_prefix=prefix)
+                config=cfg_dict, alpha=0.5, layer_prefix=prefix)
     save(f"g3_step_{fam}_{tag}.npz", arrays, meta)
 
 
@@ -389,9 +392,10 @@ def gen_block_step(is_llama, tag, wbits, abits, group, lwc, let, T=16, randomize
 # G4: learned-parameter trajectory, 2 layers x 4 samples x 2 epochs
 # --------------------------------------------------------------------------------------
 def gen_trajectory(is_llama, tag, wbits, abits, group, lwc, let, aug_loss=False,
-                   let_lr=5e-3, lwc_lr=1e-2, alpha=0.5, T=16, nsamples=4, epochs=2, n_layers=2):
+                   let_lr=5e-3, lwc_lr=1e-2, alpha=0.5, T=16, nsamples=4, epochs=2, n_layers=2, cfg_over=None):
     fam = "llama" if is_llama else "opt"
-    cfg = LlamaConfig(**LLAMA_TINY) if is_llama else OPTConfig(**OPT_TINY)
+    cfg_dict = dict(LLAMA_TINY if is_llama else OPT_TINY, **(cfg_over or {}))
+    cfg = LlamaConfig(**cfg_dict) if is_llama else OPTConfig(**cfg_dict)
     prefix = "model.layers" if is_llama else "model.decoder.layers"
     g = torch.Generator().manual_seed(23)
     layers = [llama_layer(cfg, 100 + i) if is_llama else opt_layer(cfg, 100 + i) for i in range(n_layers)]
@@ -471,7 +475,7 @@ def gen_trajectory(is_llama, tag, wbits, abits, group, lwc, let, aug_loss=False,
     arrays["norms"] = np.asarray(norms, np.float64)
     meta = dict(family=fam, wbits=wbits, abits=abits, group_size=group, lwc=lwc, let=let, aug_loss=aug_loss,
                 let_lr=let_lr, lwc_lr=lwc_lr, alpha=alpha, T=T, nsamples=nsamples, epochs=epochs,
-                n_layers=n_layers, config=LLAMA_TINY if is_llama else OPT_TINY, layer_prefix=prefix)
+                n_layers=n_layers, config=cfg_dict, layer_prefix=prefix)
     save(f"g4_traj_{fam}_{tag}.npz", arrays, meta)
 
 
@@ -533,9 +537,24 @@ def gen_act_stats():
     save("g6_act_stats.npz", arrays)
 
 
+def gen_round2():
+    """Round-2 additions: grouped-query attention (models/int_llama_layer.py:138-139 repeat_kv; the LLaMA-2-70B shape
+    class, LWC only -- LET cannot pair q/k/v rows under GQA) and one block step at head_dim 128 / T 256, the smallest
+    shape on which the HIP path's causal tile-skipping GEMM modes and fused attention kernels run."""
+    gqa = dict(num_key_value_heads=2)
+    gen_block_step(True, "gqa_w4a4_lwc", 4, 4, None, True, False, cfg_over=gqa)
+    gen_trajectory(True, "gqa_w2a16g16_lwc", 2, 16, 16, True, False, cfg_over=gqa)
+    hd128 = dict(hidden_size=256, intermediate_size=512, num_attention_heads=2, num_key_value_heads=2,
+                 max_position_embeddings=256)
+    gen_block_step(True, "hd128_w4a4_lwc_let", 4, 4, None, True, True, T=256, cfg_over=hd128, save_tmp=False)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "act_stats":
         gen_act_stats()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        gen_round2()
         sys.exit(0)
     gen_quantizer()
     gen_misc()
@@ -552,3 +571,4 @@ if __name__ == "__main__":
     gen_trajectory(False, "w4a16_lwc", 4, 16, None, True, False)
     gen_trajectory(False, "w4a4_lwc_let", 4, 4, None, True, True)
     gen_act_stats()
+    gen_round2()

@@ -50,7 +50,7 @@ def build_block(g, meta, wprefix, device, dtype):
     return q, cfg, args
 
 
-def run_block_step_parity(fname, dtype=torch.float32, device="cuda:0"):
+def run_block_step_parity(fname, dtype=torch.float32, device="cuda:0", keep_grads=False):
     """One sample-step on the HIP path vs the golden vectors of the reference.  Returns max relative errors."""
     from omniquant_amd.calibrate import register_let_parameters
     g, meta = load_golden(fname)
@@ -78,11 +78,91 @@ def run_block_step_parity(fname, dtype=torch.float32, device="cuda:0"):
     errs["out"] = rel_err(out.float(), g["out"])
     loss = torch.nn.functional.mse_loss(tgt.float(), out.float())
     errs["loss"] = abs(float(loss) - float(g["loss"].reshape(-1)[0])) / abs(float(g["loss"].reshape(-1)[0]))
+    errs["loss_value"] = float(loss)
     loss.backward()
     errs["grad"] = 0.0
     errs["per_grad"] = {}
+    errs["cos"], errs["l2"] = {}, {}          # per-tensor cosine / relative L2 error (what bf16 mode is judged by)
     for n, p in q.named_parameters():
         e = rel_err(p.grad, g["grad." + n])
         errs["per_grad"][n] = e
         errs["grad"] = max(errs["grad"], e)
+        a = p.grad.detach().double().cpu().reshape(-1)
+        b = torch.as_tensor(np.asarray(g["grad." + n])).double().reshape(-1)
+        errs["cos"][n] = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+        errs["l2"][n] = float((a - b).norm() / (b.norm() + 1e-300))
+    if keep_grads:
+        errs["grads"] = {n: p.grad.detach().float().cpu().clone() for n, p in q.named_parameters()}
     return errs
+
+
+def fp16_ulp(ref):
+    """ulp of float16 at |ref| (elementwise, numpy float64): |fp16(a) - fp16(b)| <= |a - b| + ulp."""
+    a = np.maximum(np.abs(np.asarray(ref, np.float64)), 2.0 ** -14)
+    return 2.0 ** (np.floor(np.log2(a)) - 10)
+
+
+def assert_learned_close(got, ref, what, rel=1e-3):
+    """North-star bar for a learned tensor stored in float16: 1e-3 of the tensor's magnitude plus one fp16 ulp of
+    each element (two fp32 values closer than that can still round to neighbouring float16 numbers)."""
+    got = np.asarray(got, np.float64).reshape(np.asarray(ref).shape)
+    ref = np.asarray(ref, np.float64)
+    tol = rel * max(np.abs(ref).max(), 1e-6) + fp16_ulp(ref)
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{what}: {bad.sum()}/{bad.size} beyond 1e-3*max + 1 fp16 ulp, worst {np.abs(got - ref).max():.3e} " \
+                          f"(max |ref| {np.abs(ref).max():.3e})"
+
+
+def assert_folded_close(qlayer, g, i, wbits):
+    """The folded block (models/int_llama_layer.py:315-332, 365-368) vs the fixture's folded32.*: fake-quant weights,
+    LET biases, norm parameters and the registered weight_quantizer.scales / zeros.  The block is float16 by now
+    (qlayer.half(), quantize/omniquant.py:247)."""
+    sd = dict(qlayer.named_buffers())
+    seen = 0
+    for k in [k for k in g if k.startswith(f"folded32.{i}.")]:
+        n = k[len(f"folded32.{i}."):]
+        ref = g[k].astype(np.float64)
+        if n not in sd or sd[n] is None:
+            assert np.abs(ref).max() == 0.0, f"folded32 {n} missing from the HIP block"
+            continue
+        got = sd[n].detach().double().cpu().numpy().reshape(ref.shape)
+        seen += 1
+        mx = max(np.abs(ref).max(), 1e-6)
+        if n.endswith("weight_quantizer.zeros"):
+            assert np.abs(got - ref).max() <= 1.0 and (got != ref).mean() <= 0.02, f"layer {i} {n}"
+        elif n.endswith("proj.weight") or n.endswith("fc1.weight") or n.endswith("fc2.weight"):
+            step = mx / (2 ** (wbits - 1))
+            d = np.abs(got - ref)
+            assert d.max() <= 2.5 * step and (d > 2e-3 * mx + fp16_ulp(ref)).mean() <= 0.01, f"layer {i} {n}: {d.max()}"
+        else:
+            assert_learned_close(got, ref, f"layer {i} {n}")
+    assert seen >= 14
+
+
+def oracle_block_from_step(g, meta):
+    """CPU oracle block initialised from a g3_step fixture (weights, LET statistics, the fixture's parameter values)."""
+    from oracle import ref_cpu as R
+    weights = {k[2:]: T(v) for k, v in g.items() if k.startswith("w.")}
+    spec = R.QuantSpec(meta["wbits"], meta["abits"], meta["group_size"], meta["lwc"], meta["let"])
+    blk = R.Block(meta["family"], meta["config"], weights, spec, max_pos=max(int(meta.get("T", 16)), 16))
+    if meta["let"]:
+        sc = {k[len("act_scales."):]: T(v) for k, v in g.items() if k.startswith("act_scales.")}
+        sh = {k[len("act_shifts."):]: T(v) for k, v in g.items() if k.startswith("act_shifts.")}
+        blk.register_let(sc, sh, meta["alpha"], 0, meta["layer_prefix"])
+    for n in list(blk.params.keys()):
+        blk.params[n] = T(g["p0." + n]).reshape(blk.params[n].shape).requires_grad_(True)
+    return blk
+
+
+def oracle_step_bf16_model(g, meta):
+    """One sample-step of the oracle on a fixture's inputs in the bf16 STORAGE model (fp32 arithmetic, every tensor the
+    product path materialises rounded to bf16): returns (loss, {name: grad})."""
+    blk = oracle_block_from_step(g, meta)
+    bf = torch.bfloat16
+    x, tgt, mask = T(g["x"]).to(bf).float(), T(g["target"]).to(bf).float(), T(g["mask"])
+    pos = torch.from_numpy(g["position_ids"])
+    temps = blk.temporaries(store_dtype=bf)
+    out = blk.forward(x, mask, pos, temps=temps, act_quant=True, act_dtype=bf)
+    loss = torch.nn.functional.mse_loss(tgt, out)
+    loss.backward()
+    return float(loss.detach()), {n: p.grad.detach().clone() for n, p in blk.params.items()}

@@ -9,7 +9,8 @@ import pytest
 import torch
 
 from conftest import GOLDEN, load_golden
-from gpu_helpers import T, build_block, make_args, make_cfg, rel_err, run_block_step_parity
+from gpu_helpers import (T, assert_folded_close, assert_learned_close, build_block, make_args, make_cfg, rel_err,
+                         run_block_step_parity)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -20,20 +21,67 @@ TRAJ_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, 
 
 @pytest.mark.parametrize("fname", STEP_FILES)
 def test_block_step_f32(fname):
+    """One sample-step in float32 parity mode vs the reference's vectors.  Includes a GQA block (4 heads / 2 kv heads)
+    and the head_dim-128 / T-256 block on which the causal tile-skipping GEMM modes run inside a reference-pinned step."""
     e = run_block_step_parity(fname, torch.float32, DEV)
     assert e["tmp"] < 1e-5, e          # LET temporaries + fake-quant weights
     assert e["out"] < 2e-3, e          # a handful of activation rounding ties may flip (1 level of 16)
     assert e["loss"] < 1e-3, e
-    assert e["grad"] < 3e-2, e["per_grad"]
+    assert e["grad"] < 1e-3, e["per_grad"]
 
 
 @pytest.mark.parametrize("fname", ["g3_step_llama_w4a4_lwc_let.npz", "g3_step_opt_w4a4_lwc_let.npz"])
 def test_block_step_bf16_sanity(fname):
-    """bf16 MFMA mode: same graph, looser numerics (8-bit mantissa operands)."""
+    """bf16 MFMA mode on the H=64 / T=16 toy blocks: a bf16 rounding flips 4-bit activation levels (1/15 of the range
+    each) and with 16 tokens nothing averages out, so the elementwise output error is large by construction; the loss
+    and the fake-quant weights must agree, and the gradients must still point the same way overall."""
     e = run_block_step_parity(fname, torch.bfloat16, DEV)
-    # H=64 / T=16 toy block: a bf16 rounding flips 4-bit activation levels (1/15 of the range each), so the
-    # elementwise output error is large by construction; the loss and the fake-quant weights must still agree
     assert e["tmp"] < 1e-2 and e["out"] < 0.5 and e["loss"] < 0.1, e
+    # gradients: on these toys most of them are quantisation-noise-sized and decorrelate under bf16; the large ones
+    # (the LET scales/shifts of the MLP input, the MLP clipping bounds) must still agree
+    cos = np.array(list(e["cos"].values()))
+    assert np.median(cos) > 0.8, e["cos"]
+    assert e["cos"]["fc1_smooth_scale"] > 0.99 and e["cos"]["fc1_smooth_shift"] > 0.98, e["cos"]
+
+
+def test_block_step_bf16_production_kernels_vs_reference():
+    """The production kernels (bf16 MFMA p3 GEMM incl. its causal modes, fused causal attention forward/backward, bf16
+    quantiser instantiations) inside ONE reference-pinned sample-step: the head_dim-128 / T-256 W4A4 + LET fixture.
+    bf16 activations land on the other side of a 4-bit rounding boundary for a few percent of the elements an fp32 run
+    sees, so against the fixture's fp32 vectors only the loss is held tightly (gradient agreement is printed); the
+    per-gradient bar is held against the oracle's bf16 storage model of the same step -- the oracle itself is pinned to
+    this very fixture in fp32 by tests/test_oracle_vs_golden.py."""
+    from conftest import load_golden
+    from gpu_helpers import oracle_step_bf16_model
+    from omniquant_amd import ops
+    fname = "g3_step_llama_hd128_w4a4_lwc_let.npz"
+    used = {"n": 0}
+    orig = ops.FusedCausalAttnFn.apply
+
+    class _Spy:
+        @staticmethod
+        def apply(*a):
+            used["n"] += 1
+            return orig(*a)
+    ops.FusedCausalAttnFn, keep = _Spy, ops.FusedCausalAttnFn
+    try:
+        e = run_block_step_parity(fname, torch.bfloat16, DEV, keep_grads=True)
+    finally:
+        ops.FusedCausalAttnFn = keep
+    assert used["n"] == 1, "fused attention did not run"
+    g, meta = load_golden(fname)
+    loss_m, grad_m = oracle_step_bf16_model(g, meta)
+    assert e["loss"] < 1e-2, e["loss"]                                     # vs the reference's fp32 loss
+    assert abs(e["loss_value"] - loss_m) <= 1e-2 * loss_m
+    bad = []
+    for n, got in e["grads"].items():
+        a, b = got.double().reshape(-1), grad_m[n].double().reshape(-1)
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+        l2 = float((a - b).norm() / (b.norm() + 1e-300))
+        print(f"   {n:52s} vs reference fp32: cos {e['cos'][n]:.4f} l2 {e['l2'][n]:.3f} | vs bf16 storage model: cos {cos:.4f} l2 {l2:.3f}")
+        if not (cos >= 0.99 and l2 <= 0.1):
+            bad.append((n, round(cos, 4), round(l2, 3)))
+    assert not bad, bad
 
 
 def _run_traj(fname, use_graph, dtype=torch.float32):
@@ -50,7 +98,7 @@ def _run_traj(fname, use_graph, dtype=torch.float32):
     pos = torch.from_numpy(g["position_ids"]).to(DEV)
     qlayers, omni, losses, (qi, fi) = calibrate_layers(layers, cfg, args, T(g["inps"], DEV), T(g["mask"], DEV), pos, sc, sh,
                                                        use_graph=use_graph, compute_dtype=dtype)
-    return g, m, omni, losses, qi, fi
+    return g, m, omni, losses, qi, fi, qlayers
 
 
 @pytest.mark.parametrize("fname", TRAJ_FILES)
@@ -58,27 +106,31 @@ def _run_traj(fname, use_graph, dtype=torch.float32):
 def test_trajectory_f32(fname, use_graph):
     """2 layers x 4 samples x 2 epochs of AdamW on the HIP path; learned clip/scale/shift tensors must match the
     reference within 1e-3 (north-star tolerance, relative to each tensor's magnitude)."""
-    g, m, omni, losses, qi, fi = _run_traj(fname, use_graph)
+    g, m, omni, losses, qi, fi, qlayers = _run_traj(fname, use_graph)
     ref_losses = g["losses"]
     assert len(losses) == len(ref_losses)
-    np.testing.assert_allclose(np.asarray(losses), ref_losses, rtol=2e-2)
+    np.testing.assert_allclose(np.asarray(losses), ref_losses, rtol=5e-3)
     for i in range(m["n_layers"]):
         keys = [k for k in g if k.startswith(f"omni.{i}.")]
         assert {k[len(f"omni.{i}."):] for k in keys} == set(omni[i].keys())
         for k in keys:
             n = k[len(f"omni.{i}."):]
             assert omni[i][n].dtype == torch.float16 and tuple(omni[i][n].shape) == g[k].shape
-            ref = g[k].astype(np.float64)
-            got = omni[i][n].double().numpy()
-            tol = 1e-3 * max(np.abs(ref).max(), 1e-6) + 1e-3     # fp16 storage: one ulp at |4| is 3.9e-3/2
-            assert np.abs(got - ref).max() <= tol, f"layer {i} {n}: {np.abs(got - ref).max()} > {tol}"
-        assert rel_err(fi.float(), g[f"fp_out.{m['n_layers'] - 1}"]) < 1e-3 if i == m["n_layers"] - 1 else True
-    assert rel_err(qi.float(), g[f"quant_out.{m['n_layers'] - 1}"]) < 5e-2
+            assert_learned_close(omni[i][n].double().numpy(), g[k], f"layer {i} {n}")      # 1e-3*max + 1 fp16 ulp
+            # the fixture's fp32 values before the fp16 cast (trained32.*) round to what the engine returns
+            assert_learned_close(omni[i][n].double().numpy(), g[f"trained32.{i}.{n}"], f"layer {i} trained32 {n}")
+        assert_folded_close(qlayers[i], g, i, m["wbits"])
+    last = m["n_layers"] - 1
+    assert rel_err(fi.float(), g[f"fp_out.{last}"]) < 1e-3
+    qo = g[f"quant_out.{last}"].astype(np.float64)
+    d = np.abs(qi.double().cpu().numpy() - qo)
+    # activation rounding ties may flip one 4-bit level for a few elements; everything else is tight
+    assert d.max() <= 5e-2 * np.abs(qo).max() and d.mean() <= 1e-3 * np.abs(qo).max(), (d.max(), d.mean())
 
 
 def test_trajectory_bf16_loss_curve():
     """bf16 production mode follows the reference loss curve (not elementwise-identical by construction)."""
-    g, m, omni, losses, qi, fi = _run_traj("g4_traj_llama_w4a4_lwc_let.npz", True, torch.bfloat16)
+    g, m, omni, losses, qi, fi, _ = _run_traj("g4_traj_llama_w4a4_lwc_let.npz", True, torch.bfloat16)
     ref = g["losses"]
     assert np.isfinite(losses).all()
     assert abs(np.mean(losses) - ref.mean()) / ref.mean() < 0.1
@@ -115,7 +167,7 @@ def test_sharded_engine_single_rank_matches_sequential():
             n = k[len(f"omni.{i}."):]
             ref = g[k].astype(np.float64)
             got = merged[i][n].double().numpy()
-            assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6) + 1e-3, (i, n)
+            assert_learned_close(got, ref, f"sharded layer {i} {n}")
 
 
 def test_let_init_statistics_from_teacher_pass():

@@ -45,11 +45,7 @@ def test_fakequant_vs_reference_golden(i):
             q.lowbound_factor.copy_(T(G1[f"c{i}_low"]))
     need_gx = f"c{i}_gx" in G1
     x = T(G1[f"c{i}_x"]).requires_grad_(need_gx)
-    if c["deficiency"] > 0:
-        with pytest.raises((NotImplementedError, OQError)):
-            q(x)
-        return
-    y = q(x)
+    y = q(x)      # incl. the ragged symmetric case (deficiency > 0): zero-padded last group, quantizer.py:85-87,125-128
     # scale may differ by an ulp (sigmoid/exp implementation), which can flip a rounding tie for a few elements:
     # allow <=0.2 % of elements to be off by one quantisation step, everything else tight.
     step = float(np.nanmax(G1[f"c{i}_scale"])) if not np.isnan(G1[f"c{i}_scale"]).all() else 1.0
@@ -303,9 +299,10 @@ def test_adamw_gradnorm_truncate_vs_torch():
 def test_bad_arguments_raise():
     """Error convention of the boundary: negative rc -> OQError with the library's message; CPU tensors refused."""
     from omniquant_amd import ops, OQError, _capi as C
-    x = torch.randn(4, 20, device=DEV)          # 20 % 8 != 0
-    with pytest.raises(OQError):
-        ops.fake_quant(x, 4)
+    x = torch.randn(4, 20, device=DEV)          # 20 % 8 != 0: served by the generic-segment kernels, not an error
+    assert ops.fake_quant(x, 4).shape == x.shape
+    with pytest.raises(OQError):                # ... which have no LET transform
+        ops.fake_quant(x, 4, col_mul=torch.ones(20, device=DEV))
     with pytest.raises(OQError):
         ops.fake_quant(torch.randn(4, 64), 4)   # CPU tensor
     with pytest.raises(OQError):
@@ -535,3 +532,70 @@ def test_gemm_addend_and_sibling_projections(dtype):
     assert float((xa.grad.float() - xb.grad.float()).abs().max()) <= tol * float(xa.grad.float().abs().max())
     for a, b in zip(wa, wb):
         assert torch.equal(a.grad, b.grad)
+
+
+@pytest.mark.parametrize("rows,cols,seg,sym", [(16, 252, None, False), (8, 256, 96, True), (8, 192, 96, False),
+                                               (4, 8 * 512 * 8 + 8, None, False), (6, 100, 40, True), (5, 77, 7, False)])
+@pytest.mark.parametrize("nbits", [2, 4])
+def test_fakequant_generic_segments_vs_oracle(rows, cols, seg, sym, nbits):
+    """Segmentations the vector kernels do not take (row length not a multiple of 8, groups that are not 8*2^k wide,
+    ragged last group = zero-padded, rows longer than 32768) run the generic one-wave-per-segment kernels: forward,
+    LWC gradients and input gradient vs the CPU oracle (quantize/quantizer.py:84-147 incl. :85-87,:125-128)."""
+    from oracle import ref_cpu as R
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(rows * cols + nbits)
+    x = torch.randn(rows, cols, generator=g)
+    if seg and cols % seg:
+        x[1] = -x[1].abs()            # an all-negative ragged group: its amax is the padding zero
+        x[2] = x[2].abs()
+    nseg = rows * (-(-cols // (seg or cols)))
+    up = 4 + torch.randn(nseg, 1, generator=g)
+    low = 4 + torch.randn(nseg, 1, generator=g)
+    G = torch.randn(rows, cols, generator=g)
+    if seg and cols % seg and not sym:
+        pytest.skip("ragged groups are symmetric-only in the reference (quantizer.py:69)")
+    xo, uo, lo_ = x.clone().requires_grad_(True), up.clone().requires_grad_(True), low.clone().requires_grad_(True)
+    yo, so, zo = R.fake_quant(xo, nbits, seg, uo, lo_, sym, return_qparams=True)
+    (yo * G).sum().backward()
+    xd, ud, ld = (t.clone().to(DEV).requires_grad_(True) for t in (x, up, low))
+    stash = {}
+    yd = ops.fake_quant(xd, nbits, seg, ud, ld, sym, None, stash)
+    assert_close(stash["scale"], so.detach().numpy(), 2e-6, 1e-9, "scale")
+    assert_close(stash["zp"], zo.detach().numpy(), 0, 0, "zp", max_bad_frac=0.01)
+    assert_close(yd, yo.detach().numpy(), 1e-5, 1e-6, "y", max_bad_frac=0.005)
+    (yd * G.to(DEV)).sum().backward()
+    sc = max(float(uo.grad.abs().max()), float(lo_.grad.abs().max()), 1e-6)
+    assert_close(ud.grad, uo.grad.numpy(), 2e-3, 1e-3 * sc, "gup", max_bad_frac=0.02)
+    assert_close(ld.grad, lo_.grad.numpy(), 2e-3, 1e-3 * sc, "glow", max_bad_frac=0.02)
+    assert_close(xd.grad, xo.grad.numpy(), 1e-4, 1e-4, "gx", max_bad_frac=0.005)
+
+
+def test_identity_grid_keeps_the_let_transform():
+    """n_bits >= 16: the reference's quantizer returns its input unchanged (quantizer.py:109-110), so with LET the
+    temporary weight is just the transformed weight and the gradients are those of the transform alone."""
+    from omniquant_amd.quantizer import UniformAffineQuantizer
+    g = torch.Generator().manual_seed(3)
+    rows, cols = 48, 512
+    W = (torch.randn(rows, cols, generator=g) * 0.05).half()
+    cm, rd, rm = (torch.rand(n, generator=g) + 0.5 for n in (cols, rows, rows))
+    sh = torch.randn(cols, generator=g) * 0.1
+    G, Gs = torch.randn(rows, cols, generator=g), torch.randn(rows, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (cm, rd, rm, sh)]
+    xo = ((W.float() * leaves[0].view(1, -1)) / leaves[1].view(-1, 1)) * leaves[2].view(-1, 1)
+    wso = W.float() @ leaves[3]
+    ((xo * G).sum() + (wso * Gs).sum()).backward()
+    q = UniformAffineQuantizer(n_bits=16, per_channel_axes=[0], dynamic_method="per_channel", shape=(rows, cols), lwc=True).to(DEV)
+    dl = [t.clone().to(DEV).requires_grad_(True) for t in (cm, rd, rm, sh)]
+    y, ws = q.quantize(W.to(DEV), out_dtype=torch.float32, col_mul=dl[0], row_div=dl[1], row_mul=dl[2], shift=dl[3])
+    assert q.scale is None and q.round_zero_point is None
+    assert_close(y, xo.detach().numpy(), 1e-6, 1e-9, "identity y")
+    assert_close(ws, wso.detach().numpy(), 1e-4, 1e-6, "wshift")
+    ((y * G.to(DEV)).sum() + (ws * Gs.to(DEV)).sum()).backward()
+    for n, a, b in zip(("col_mul", "row_div", "row_mul", "shift"), dl, leaves):
+        sc = float(b.grad.abs().max())
+        assert_close(a.grad / sc, b.grad.numpy() / sc, 1e-3, 1e-4, "grad " + n)
+    assert q.upbound_factor.grad is None
+    w16 = q.quantize(W.to(DEV), out_dtype=torch.bfloat16)             # no LET: the weight itself, cast
+    assert w16.dtype == torch.bfloat16 and torch.equal(w16, W.to(DEV).to(torch.bfloat16))
+    q.register_scales_and_zeros()                                     # tolerates scale = None like the reference
+    assert q.scales is None and q.zeros is None

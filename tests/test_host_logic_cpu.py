@@ -25,6 +25,15 @@ def test_mask_is_causal_rules():
     m2[0, 1] = 0.0                                          # edited in place after it was cached: version counter invalidates
     assert not ops.mask_is_causal(m2)
     assert not ops.mask_is_causal(torch.triu(torch.full((128, 128), -1e4), 1))   # -1e4 is not "exactly masked"
+    # the mask transformers builds for an fp16 model (what the reference's Catcher records, quantize/omniquant.py:89-113):
+    # finfo(float16).min above the diagonal, batch of identical masks
+    hf = torch.triu(torch.full((256, 256), torch.finfo(torch.float16).min, dtype=torch.float16), 1)[None, None]
+    assert ops.mask_is_causal(hf) and ops.mask_is_causal(hf.float().expand(2, -1, -1, -1))
+    pad = hf.float().repeat(2, 1, 1, 1)
+    pad[1, 0, :, :3] = torch.finfo(torch.float16).min       # sample 1 is left-padded: not the plain causal mask
+    assert not ops.mask_is_causal(pad)
+    # slices of one batched mask are judged one by one (the verdict is cached per view window, not per base tensor)
+    assert ops.mask_is_causal(pad[:1]) and not ops.mask_is_causal(pad[1:]) and ops.mask_is_causal(pad[:1])
 
 
 def test_engine_defaults_match_reference_cli():

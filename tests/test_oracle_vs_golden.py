@@ -144,6 +144,40 @@ def test_trajectory(fname):
             tol = 1e-3 * max(np.abs(ref).max(), 1e-6)
             assert np.abs(got - ref).max() <= tol + 1e-3 * 0, f"{n}: {np.abs(got-ref).max()} > {tol}"
         close(res["quant_out"][i], g[f"quant_out.{i}"], rtol=5e-2, atol=5e-2, what=f"quant_out {i}")
+        # ---- fp32 learned tensors before the fp16 cast (trained32.*) -----------------------------------------------
+        for k in [k for k in g if k.startswith(f"trained32.{i}.")]:
+            n = k[len(f"trained32.{i}."):]
+            ref = g[k].astype(np.float64)
+            got = res["trained"][i][n].double().numpy().reshape(ref.shape)
+            assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6), f"trained32 {n}"
+        # ---- the folded model (models/int_llama_layer.py:315-332,365-368): weights, LET biases, norm parameters,
+        #      weight_quantizer.scales / zeros as registered by register_scales_and_zeros --------------------------------
+        fold = res["folded"][i]
+        for k in [k for k in g if k.startswith(f"folded32.{i}.")]:
+            n = k[len(f"folded32.{i}."):]
+            ref = g[k].astype(np.float64)
+            if n.endswith("weight_quantizer.scales") or n.endswith("weight_quantizer.zeros"):
+                lin = n.rsplit(".weight_quantizer.", 1)[0]
+                sc_, zp_ = res["qparams"][i][lin]
+                got = (sc_ if n.endswith("scales") else zp_).double().numpy().reshape(ref.shape)
+                if n.endswith("zeros"):
+                    # an integer: a 1e-3-level difference in the learned bounds may move it by one for a few rows
+                    assert np.abs(got - ref).max() <= 1.0 and (got != ref).mean() <= 0.02, f"folded zeros {n}"
+                else:
+                    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), f"folded scales {n}"
+                continue
+            if n not in fold:
+                assert np.abs(ref).max() == 0.0, f"folded32 {n} missing from the oracle's fold"
+                continue
+            got = fold[n].double().numpy().reshape(ref.shape)
+            if n.endswith("proj.weight") or n.endswith("fc1.weight") or n.endswith("fc2.weight"):
+                # fake-quantised values: equal up to 1e-3 of the tensor except the few elements whose rounding decision
+                # flipped (one quantisation step)
+                step = np.abs(ref).max() / (2 ** (m["wbits"] - 1))
+                d = np.abs(got - ref)
+                assert d.max() <= 2.5 * step and (d > 2e-3 * np.abs(ref).max()).mean() <= 0.01, f"folded weight {n}"
+            else:
+                assert np.abs(got - ref).max() <= 1e-3 * max(np.abs(ref).max(), 1e-6), f"folded {n}"
 
 
 def test_act_stats_vs_reference_prepass():

@@ -84,3 +84,47 @@ def test_sharded_protocol_two_ranks_gloo():
         t = merged[1][n]
         assert t.dtype == torch.float16 and tuple(t.shape) == g[k].shape and torch.isfinite(t).all()
         assert np.abs(t.double().numpy() - g[k].astype(np.float64)).max() < 0.5
+
+
+def _pipe_worker(rank, world, initfile, outdir, chunk):
+    sys.path.insert(0, ROOT)
+    from omniquant_amd.parallel import pipeline_teacher_boundaries, shard_bounds
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    inps = torch.randn(7, 5, 8, generator=g)              # 7 samples: the last message is ragged for chunk 2 and 3
+    calls = []
+
+    def teacher(lo, hi, bank):                             # "layer i": x -> tanh(x) * (i + 2) + i, per sample
+        calls.append(bank.shape[0])
+        for i in range(lo, hi):
+            bank = torch.tanh(bank) * (i + 2) + i
+        return bank
+
+    lo, hi = shard_bounds(5, world, rank)                  # 5 layers over 3 ranks: 2 + 2 + 1
+    bank = pipeline_teacher_boundaries(inps, lo, hi, teacher, None, chunk)
+    torch.save({"bank": bank, "calls": calls, "bounds": (lo, hi)}, os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunk", [None, 2, 3, 100])
+def test_chunked_teacher_pipeline_three_ranks_gloo(chunk):
+    """The streamed pre-pass hands every rank exactly the activations the sequential chain produces at its boundary,
+    for any message size (one message, ragged last message, message larger than the bank), and a rank forwards one
+    message at a time (so its successor can start after the first one)."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_pipe_worker, args=(3, os.path.join(d, "init"), d, chunk), nprocs=3, join=True)
+        outs = [torch.load(os.path.join(d, f"r{r}.pt"), weights_only=True) for r in range(3)]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(7, 5, 8, generator=g)
+    expect = [x.clone()]
+    for i in range(5):
+        x = torch.tanh(x) * (i + 2) + i
+        expect.append(x.clone())
+    for r, o in enumerate(outs):
+        lo, hi = o["bounds"]
+        assert torch.equal(o["bank"], expect[lo]), f"rank {r}: wrong boundary bank"
+    n_msg = 1 if (chunk is None or chunk >= 7) else -(-7 // chunk)
+    assert len(outs[0]["calls"]) == n_msg and len(outs[1]["calls"]) == n_msg and outs[2]["calls"] == []
+    assert sum(outs[0]["calls"]) == 7
