@@ -11,151 +11,12 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "oq_common.h"
+#include "oq_quant_dev.h"
 
 namespace {
 
 constexpr int64_t OQ_FQ_BWD_MAX_BLOCKS = 512;   // workgroups when column partials are written
 constexpr int64_t OQ_FQ_MAX_BLOCKS = 1024;      // otherwise: >= 2-4 rows per workgroup so the prefetch pipelines
-
-struct FQ {
-    const void* w;
-    int64_t rows, cols, seg;
-    int nbits, symmetric;
-    float inv_q;          // 1 / (2^nbits - 1), correctly rounded on the host
-    const float *col_mul, *row_div, *row_mul, *shift, *up, *low;
-    // fwd
-    void* y;
-    float *scale, *zp, *xmin, *xmax, *wshift;      // bwd READS xmin / xmax (written by the forward)
-    // bwd
-    const void* g;
-    const float* g_wshift;
-    float *g_up, *g_low;
-    void* gx;
-    float *g_col_mul, *g_shift, *g_row_div, *g_row_mul;
-    float* ws;   // bwd workspace: [2][gridDim.x][cols] per-workgroup column partials
-};
-
-// block-wide reduction of up to 3 values; op: 0 sum, 1 max, 2 min.  All threads must call.
-// block-wide reduction of up to 4 values; op: 0 sum, 1 max, 2 min.  All threads must call.  The cross-wave step reads
-// the (at most 8) per-wave partials of a value with one or two ds_read_b128 and combines them unconditionally: slots of
-// waves that do not exist hold the operation's identity (written once by red_init), so there is no runtime loop.
-// Every call site owns its `red` region (the identities are per operation).
-__device__ __forceinline__ float red_identity(int op) { return op == 0 ? 0.f : (op == 1 ? -INFINITY : INFINITY); }
-
-template <int NV>
-__device__ __forceinline__ void red_init(const int (&op)[NV], float* red /*[NV*8]*/) {
-    if (threadIdx.x < NV * 8) red[threadIdx.x] = red_identity(op[threadIdx.x >> 3]);
-}
-
-template <int NV>
-__device__ __forceinline__ void block_reduce(float (&v)[NV], const int (&op)[NV], float* red /*[NV*8], red_init'ed*/,
-                                             unsigned wave_uniform = 0 /* bit i: v[i] is already a per-wave value */) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        if ((wave_uniform >> i) & 1) continue;
-        v[i] = op[i] == 0 ? wave_sum(v[i]) : (op[i] == 1 ? wave_max(v[i]) : wave_min(v[i]));
-    }
-    if (nw == 1) return;
-    __syncthreads();   // protect `red` from the previous use
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) red[i * 8 + wid] = v[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(red + i * 8);
-        float r;
-        if (op[i] == 0) r = (a[0] + a[1]) + (a[2] + a[3]);
-        else if (op[i] == 1) r = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
-        else r = fminf(fminf(a[0], a[1]), fminf(a[2], a[3]));
-        if (nw > 4) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(red + i * 8 + 4);
-            if (op[i] == 0) r += (b[0] + b[1]) + (b[2] + b[3]);
-            else if (op[i] == 1) r = fmaxf(r, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
-            else r = fminf(r, fminf(fminf(b[0], b[1]), fminf(b[2], b[3])));
-        }
-        v[i] = r;
-    }
-}
-
-struct QP {
-    float s, z, su, sl, hi, lo;
-};
-
-// x / d for the LET row factor: reciprocal + one fma-residual correction (3 VALU ops instead of the ~10-op IEEE
-// expansion whose v_div_* / v_rcp ops made these kernels VALU-bound).  Forward and backward use the SAME function,
-// so x, its min/max, ties and the clip mask are self-consistent; vs. an IEEE divide the result differs by <= 1 ulp
-// in rare cases, which is below the ulp-level differences sigmoid/exp already introduce.
-__device__ __forceinline__ float div_nr(float a, float d, float inv_d) {
-    const float q = a * inv_d;
-    const float r = fmaf(-q, d, a);
-    return fmaf(r, inv_d, q);
-}
-
-// rne(x / s) evaluated as rne(x * (1/s)) -- bit-identical to the IEEE quotient's rounding except when x/s lies within
-// ~2 ulp of a half-integer; those (rare) lanes redo the exact division, so the result equals rintf(x / s) always.
-__device__ __forceinline__ float rne_div(float x, float s, float inv_s, float* tq) {
-    float t = x * inv_s;
-    float r = rintf(t);
-    if (fabsf(t - r) > fmaf(-4e-7f, fabsf(t), 0.5f)) {
-        t = x / s;
-        r = rintf(t);
-    }
-    *tq = t;
-    return r;
-}
-
-// round_ste forward exactly as the reference composes it, (round(t) - t) + t: equals rintf(t) for every finite t
-// and turns +-inf (scale == 0, quirk Q1) into NaN like the reference does.
-__device__ __forceinline__ float rne_ste(float t) {
-    const float r = rintf(t);
-    return (r - t) + t;
-}
-
-// Scale / zero-point of one segment.  The asymmetric branch avoids the ~12-instruction IEEE division expansion (every
-// thread of the row runs this once per row): (hs-ls)/Q is formed by the Markstein sequence q0 = a*(1/Q),
-// q1 = fma(fma(-q0, Q, a), 1/Q, q0), which is the correctly rounded quotient for the integer divisors 2^n-1 used here
-// (1/Q correctly rounded, exact fma residual); the zero-point uses the reciprocal-multiply + exact fallback of rne_div.
-// `inv_s` is only ever used inside rne_div-style verified rounding, so v_rcp_f32 (1 ulp) is accurate enough.
-__device__ __forceinline__ QP make_qp(float hi, float lo, bool lwc, float up_logit, float low_logit, int nbits,
-                                      int symmetric, float invQ, float* inv_s_out) {
-    QP q;
-    q.hi = hi;
-    q.lo = lo;
-    q.su = lwc ? sigmoidf_(up_logit) : 1.0f;
-    q.sl = lwc ? sigmoidf_(low_logit) : 1.0f;
-    const float hs = lwc ? q.su * hi : hi;
-    const float ls = lwc ? q.sl * lo : lo;
-    if (symmetric) {
-        const float lv = (float)((1 << (nbits - 1)) - 1);
-        float s = fmaxf(fabsf(hs), fabsf(ls)) / lv;
-        if (hs != hs || ls != ls) s = hs + ls;               // keep NaN
-        q.s = (s != s) ? s : fminf(fmaxf(s, 1e-5f), 1e4f);
-        q.z = lv;
-        *inv_s_out = __builtin_amdgcn_rcpf(q.s);
-    } else {
-        const float Q = (float)((1 << nbits) - 1);
-        const float a = hs - ls;
-        const float q0 = a * invQ;
-        float sc = fmaf(fmaf(-q0, Q, a), invQ, q0);          // == a / Q (not clamped: reference quirk Q1)
-        if (!(fabsf(a) >= 1e-30f && fabsf(a) <= 1e30f)) sc = a / Q;   // zero / tiny / huge / NaN: plain division
-        q.s = sc;
-        const float inv_s = __builtin_amdgcn_rcpf(sc);
-        *inv_s_out = inv_s;
-        float zp = -ls * inv_s;
-        const float rz = rintf(zp);
-        if (!(fabsf(zp - rz) <= fmaf(-4e-7f, fabsf(zp), 0.5f)) || !(fabsf(zp) < 9.9e3f)) {
-            zp = -ls / sc;                                   // near a rounding boundary, at the clamp, inf or NaN
-            zp = (zp != zp) ? zp : fminf(fmaxf(zp, -1e4f), 1e4f);
-            q.z = rintf(zp);
-        } else {
-            q.z = rz;
-        }
-    }
-    return q;
-}
 
 // ---------------------------------------------------------------------------------------------------
 // forward
@@ -956,6 +817,10 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = wshift ? shift : nullptr;
     p.up = up; p.low = low; p.y = y; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax; p.wshift = wshift;
+    {   // whole-row segments: the wave-per-row kernels (oq_rowq.hip) take them when the shape is theirs
+        const int rq = oq_rowq_fwd(p, w_dtype, y_dtype, stream);
+        if (rq <= 0) return rq;
+    }
     const bool let = col_mul || row_div || row_mul || shift;
     int ch, bt;
     row_geometry(cols, 2, &ch, &bt);
@@ -1055,6 +920,19 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
     p.g = g; p.g_wshift = g_wshift; p.g_up = g_up; p.g_low = g_low; p.gx = gx;
     p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax);
     p.g_col_mul = g_col_mul; p.g_shift = g_shift; p.g_row_div = g_row_div; p.g_row_mul = g_row_mul;
+    {   // whole-row segments: the wave-per-row kernels (oq_rowq.hip) take them when the shape is theirs
+        int64_t parts = 0;
+        const int rq = oq_rowq_bwd(p, w_dtype, g_dtype, workspace, workspace_floats, &parts, stream);
+        if (rq < 0) return rq;
+        if (rq == 0) {
+            if (parts > 0) {
+                const dim3 rg((unsigned)((cols + 15) / 16), 2);
+                hipLaunchKernelGGL(colreduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace, (int)parts, cols, g_col_mul, g_shift);
+                OQ_CHECK_LAUNCH("oq_fakequant_bwd(colreduce)");
+            }
+            return OQ_OK;
+        }
+    }
     // the LET instantiation is needed whenever the transform is present (x must be recomputed), not only for its grads
     const bool let = col_mul || row_div || row_mul || g_col_mul || g_shift || g_row_div || g_row_mul;
     int ch, bt;
@@ -1089,6 +967,8 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
 
 extern "C" int64_t oq_fakequant_bwd_workspace(int64_t rows, int64_t cols) {
     const int64_t cap = dbg_env("OQ_DBG_FQ_BWD_BLOCKS", OQ_FQ_BWD_MAX_BLOCKS);
-    const int64_t grid = rows < cap ? rows : cap;
+    int64_t grid = rows < cap ? rows : cap;
+    const int64_t rq = oq_rowq_bwd_blocks(rows, cols);      // the wave-per-row kernels write one partial row per workgroup
+    if (rq > grid) grid = rq;
     return 2 * grid * cols;
 }

@@ -1,0 +1,161 @@
+// Device helpers shared by the quantiser kernels (oq_quant.hip: segment kernels; oq_rowq.hip: wave-per-row kernels).
+// Everything here restates quantize/quantizer.py:84-147 arithmetic; both kernel families MUST use these functions so that
+// forward, backward and the two families agree bit for bit on scale / zero-point / rounding decisions.
+#pragma once
+#include <type_traits>
+#include "oq_common.h"
+
+// One description of a fake-quant problem (forward and backward share it).  Plain struct with external linkage: it is
+// passed between oq_quant.hip and oq_rowq.hip.
+struct FQ {
+    const void* w;
+    int64_t rows, cols, seg;
+    int nbits, symmetric;
+    float inv_q;          // 1 / (2^nbits - 1), correctly rounded on the host
+    const float *col_mul, *row_div, *row_mul, *shift, *up, *low;
+    // fwd
+    void* y;
+    float *scale, *zp, *xmin, *xmax, *wshift;      // bwd READS xmin / xmax (written by the forward)
+    // bwd
+    const void* g;
+    const float* g_wshift;
+    float *g_up, *g_low;
+    void* gx;
+    float *g_col_mul, *g_shift, *g_row_div, *g_row_mul;
+    float* ws;   // bwd workspace: [2][gridDim.x][cols] per-workgroup column partials
+};
+
+namespace {
+
+
+// block-wide reduction of up to 3 values; op: 0 sum, 1 max, 2 min.  All threads must call.
+// block-wide reduction of up to 4 values; op: 0 sum, 1 max, 2 min.  All threads must call.  The cross-wave step reads
+// the (at most 8) per-wave partials of a value with one or two ds_read_b128 and combines them unconditionally: slots of
+// waves that do not exist hold the operation's identity (written once by red_init), so there is no runtime loop.
+// Every call site owns its `red` region (the identities are per operation).
+__device__ __forceinline__ float red_identity(int op) { return op == 0 ? 0.f : (op == 1 ? -INFINITY : INFINITY); }
+
+template <int NV>
+__device__ __forceinline__ void red_init(const int (&op)[NV], float* red /*[NV*8]*/) {
+    if (threadIdx.x < NV * 8) red[threadIdx.x] = red_identity(op[threadIdx.x >> 3]);
+}
+
+template <int NV>
+__device__ __forceinline__ void block_reduce(float (&v)[NV], const int (&op)[NV], float* red /*[NV*8], red_init'ed*/,
+                                             unsigned wave_uniform = 0 /* bit i: v[i] is already a per-wave value */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        if ((wave_uniform >> i) & 1) continue;
+        v[i] = op[i] == 0 ? wave_sum(v[i]) : (op[i] == 1 ? wave_max(v[i]) : wave_min(v[i]));
+    }
+    if (nw == 1) return;
+    __syncthreads();   // protect `red` from the previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[i * 8 + wid] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(red + i * 8);
+        float r;
+        if (op[i] == 0) r = (a[0] + a[1]) + (a[2] + a[3]);
+        else if (op[i] == 1) r = fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3]));
+        else r = fminf(fminf(a[0], a[1]), fminf(a[2], a[3]));
+        if (nw > 4) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(red + i * 8 + 4);
+            if (op[i] == 0) r += (b[0] + b[1]) + (b[2] + b[3]);
+            else if (op[i] == 1) r = fmaxf(r, fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+            else r = fminf(r, fminf(fminf(b[0], b[1]), fminf(b[2], b[3])));
+        }
+        v[i] = r;
+    }
+}
+
+struct QP {
+    float s, z, su, sl, hi, lo;
+};
+
+// x / d for the LET row factor: reciprocal + one fma-residual correction (3 VALU ops instead of the ~10-op IEEE
+// expansion whose v_div_* / v_rcp ops made these kernels VALU-bound).  Forward and backward use the SAME function,
+// so x, its min/max, ties and the clip mask are self-consistent; vs. an IEEE divide the result differs by <= 1 ulp
+// in rare cases, which is below the ulp-level differences sigmoid/exp already introduce.
+__device__ __forceinline__ float div_nr(float a, float d, float inv_d) {
+    const float q = a * inv_d;
+    const float r = fmaf(-q, d, a);
+    return fmaf(r, inv_d, q);
+}
+
+// rne(x / s) evaluated as rne(x * (1/s)) -- bit-identical to the IEEE quotient's rounding except when x/s lies within
+// ~2 ulp of a half-integer; those (rare) lanes redo the exact division, so the result equals rintf(x / s) always.
+__device__ __forceinline__ float rne_div(float x, float s, float inv_s, float* tq) {
+    float t = x * inv_s;
+    float r = rintf(t);
+    if (fabsf(t - r) > fmaf(-4e-7f, fabsf(t), 0.5f)) {
+        t = x / s;
+        r = rintf(t);
+    }
+    *tq = t;
+    return r;
+}
+
+// round_ste forward exactly as the reference composes it, (round(t) - t) + t: equals rintf(t) for every finite t
+// and turns +-inf (scale == 0, quirk Q1) into NaN like the reference does.
+__device__ __forceinline__ float rne_ste(float t) {
+    const float r = rintf(t);
+    return (r - t) + t;
+}
+
+// Scale / zero-point of one segment.  The asymmetric branch avoids the ~12-instruction IEEE division expansion (every
+// thread of the row runs this once per row): (hs-ls)/Q is formed by the Markstein sequence q0 = a*(1/Q),
+// q1 = fma(fma(-q0, Q, a), 1/Q, q0), which is the correctly rounded quotient for the integer divisors 2^n-1 used here
+// (1/Q correctly rounded, exact fma residual); the zero-point uses the reciprocal-multiply + exact fallback of rne_div.
+// `inv_s` is only ever used inside rne_div-style verified rounding, so v_rcp_f32 (1 ulp) is accurate enough.
+__device__ __forceinline__ QP make_qp(float hi, float lo, bool lwc, float up_logit, float low_logit, int nbits,
+                                      int symmetric, float invQ, float* inv_s_out) {
+    QP q;
+    q.hi = hi;
+    q.lo = lo;
+    q.su = lwc ? sigmoidf_(up_logit) : 1.0f;
+    q.sl = lwc ? sigmoidf_(low_logit) : 1.0f;
+    const float hs = lwc ? q.su * hi : hi;
+    const float ls = lwc ? q.sl * lo : lo;
+    if (symmetric) {
+        const float lv = (float)((1 << (nbits - 1)) - 1);
+        float s = fmaxf(fabsf(hs), fabsf(ls)) / lv;
+        if (hs != hs || ls != ls) s = hs + ls;               // keep NaN
+        q.s = (s != s) ? s : fminf(fmaxf(s, 1e-5f), 1e4f);
+        q.z = lv;
+        *inv_s_out = __builtin_amdgcn_rcpf(q.s);
+    } else {
+        const float Q = (float)((1 << nbits) - 1);
+        const float a = hs - ls;
+        const float q0 = a * invQ;
+        float sc = fmaf(fmaf(-q0, Q, a), invQ, q0);          // == a / Q (not clamped: reference quirk Q1)
+        if (!(fabsf(a) >= 1e-30f && fabsf(a) <= 1e30f)) sc = a / Q;   // zero / tiny / huge / NaN: plain division
+        q.s = sc;
+        const float inv_s = __builtin_amdgcn_rcpf(sc);
+        *inv_s_out = inv_s;
+        float zp = -ls * inv_s;
+        const float rz = rintf(zp);
+        if (!(fabsf(zp - rz) <= fmaf(-4e-7f, fabsf(zp), 0.5f)) || !(fabsf(zp) < 9.9e3f)) {
+            zp = -ls / sc;                                   // near a rounding boundary, at the clamp, inf or NaN
+            zp = (zp != zp) ? zp : fminf(fmaxf(zp, -1e4f), 1e4f);
+            q.z = rintf(zp);
+        } else {
+            q.z = rz;
+        }
+    }
+    return q;
+}
+
+
+}  // namespace
+
+// wave-per-row kernels (oq_rowq.hip).  Return OQ_OK when they took the problem, 1 when the shape is not theirs (the
+// caller then runs the segment kernels), or a negative OQ_E_* code.
+int oq_rowq_fwd(const FQ& p, int w_dtype, int y_dtype, void* stream);
+int oq_rowq_bwd(const FQ& p, int w_dtype, int g_dtype, float* workspace, int64_t workspace_floats, int64_t* partial_rows,
+                void* stream);
+int64_t oq_rowq_bwd_blocks(int64_t rows, int64_t cols);     // workgroups that write column partials (workspace rows)

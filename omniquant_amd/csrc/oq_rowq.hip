@@ -1,0 +1,590 @@
+// UniformAffineQuantizer, whole-row segments (per-channel weights, per-token activations), wave-per-row kernels.
+//
+// Replaces the same reference lines as oq_quant.hip (quantize/quantizer.py:84-147 + the weight side of
+// models/transformation.py:24-69) for the case "one segment = one row" with rows of 512 .. 32768 elements.
+//
+// Why a second kernel family: the segment kernels of oq_quant.hip give a row to a whole WORKGROUP (16 elements per lane,
+// two workgroup barriers per row).  rocprofv3 (profiles/r2_quant_sq_before.txt) showed them neither HBM- nor
+// VALU-throughput-bound: 250 VGPRs -> 2 waves per SIMD, 44-67 VALU instructions per element (per-row work repeated by
+// every wave for 16 elements), 41-44 % of the wave time in s_waitcnt / s_barrier.  Here a row belongs to ONE wave (or 2,
+// 4, 8 waves for rows longer than 4096): 32-64 elements per lane amortise the per-row arithmetic, waves never wait for
+// each other (rows <= 4096) and every wave keeps 8-16 KB of loads in flight.
+//   * LET column vectors (col_mul, shift) live in LDS, staged once per workgroup;
+//   * the backward's column gradients (g_col_mul, g_shift) are accumulated in LDS: each wave updates its OWN
+//     accumulator slab with 16-byte LDS reads/writes (one wave per address, program order: deterministic), the slabs of
+//     a workgroup are summed in a fixed order at the end and written as one partial row per workgroup (finished by
+//     colreduce_kernel);
+//   * the straight-through terms through max / min touch only the chunks that hold an element equal to the row max /
+//     min: a scalar flag per chunk (from the tie-count compares) selects them, everything else is written in the main pass.
+// Arithmetic (scale, zero-point, rounding with the exact-division fallback, tie sharing) is shared with oq_quant.hip
+// through oq_quant_dev.h, so both families give identical values.
+#include <stdlib.h>
+#include "oq_common.h"
+#include "oq_quant_dev.h"
+
+namespace {
+
+int64_t env_i(const char* n, int64_t d) {
+    const char* v = getenv(n);
+    return v ? atoll(v) : d;
+}
+
+struct RowGeo {
+    int nw;     // waves per row (1, 2, 4, 8)
+    int chn;    // 16-byte chunks per lane actually used (<= 8)
+    int wpb;    // waves per workgroup
+};
+
+// rows of 512 .. 32768 elements, multiple of 8
+bool row_geo(int64_t cols, int force_nw, RowGeo* g) {
+    if (cols % 8 != 0 || cols < 512 || cols > 32768) return false;
+    const int64_t chunks = cols / 8;
+    int nw = force_nw > 0 ? force_nw : 1;
+    while (nw <= 8 && (chunks + 64 * nw - 1) / (64 * nw) > 8) nw <<= 1;
+    if (nw > 8 || (nw & (nw - 1))) return false;
+    g->nw = nw;
+    g->chn = (int)((chunks + 64 * nw - 1) / (64 * nw));
+    g->wpb = nw > 4 ? 8 : 4;
+    return true;
+}
+
+// acc[plane][chunk slot][4] += v[4 * plane .. ]: a wave's private accumulator slab, updated with plain 16-byte LDS reads
+// and writes (only the owning wave touches it, in program order: deterministic).  The two planes keep consecutive lanes on
+// consecutive 16-byte slots, which is conflict-free for ds_read_b128 / ds_write_b128.  (ds_add_f32 was tried first: one
+// LDS atomic per element and vector made the kernel 4x SLOWER than the register-accumulator version it replaced.)
+__device__ __forceinline__ void slab_add(float* slab, int plane_stride, int slot, const float (&v)[8]) {
+    f32x4* p0 = reinterpret_cast<f32x4*>(slab) + slot;
+    f32x4* p1 = reinterpret_cast<f32x4*>(slab + plane_stride) + slot;
+    f32x4 a = *p0, b = *p1;
+    a += f32x4{v[0], v[1], v[2], v[3]};
+    b += f32x4{v[4], v[5], v[6], v[7]};
+    *p0 = a;
+    *p1 = b;
+}
+
+// cross-wave exchange of 4 per-row values among the nw waves of a row (double-buffered: one barrier per row)
+__device__ __forceinline__ void row_exchange(float* red, int& par, int wid, int rslot, int nw, int lane, float (&v)[4],
+                                             const int (&op)[4]) {
+    float* rr = red + par * 32;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rr[wid * 4 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = op[k] == 0 ? 0.f : (op[k] == 1 ? -INFINITY : INFINITY);
+    for (int i = 0; i < nw; ++i) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(rr + (rslot * nw + i) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = op[k] == 0 ? v[k] + q[k] : (op[k] == 1 ? fmaxf(v[k], q[k]) : fminf(v[k], q[k]));
+    }
+    par ^= 1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------
+template <typename TIN, typename TOUT, bool LET, int CH>
+__global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int rpb = wpb / nw;
+    const int rslot = wid / nw, wsub = wid - rslot * nw;
+    const int K = (int)p.cols;
+    const int nchunks = K >> 3;
+    float* cm_s = smem;
+    float* sh_s = smem + K;
+    float* red = smem + (LET ? 2 * K : 0);
+    const float Q = (float)((1 << p.nbits) - 1);
+    if constexpr (LET) {
+        for (int i = threadIdx.x * 4; i < K; i += blockDim.x * 4) {
+            *reinterpret_cast<f32x4*>(cm_s + i) = p.col_mul ? *reinterpret_cast<const f32x4*>(p.col_mul + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+            *reinterpret_cast<f32x4*>(sh_s + i) = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();
+    }
+    bool valid[CH];
+    int cc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = (j * nw + wsub) * 64 + lane;
+        valid[j] = c < nchunks;
+        cc[j] = (valid[j] ? c : nchunks - 1) * 8;     // surplus lanes redo the last chunk (benign duplicate stores)
+    }
+    const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
+    TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
+    const bool lwc = p.up != nullptr;
+    int par = 0;
+    for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
+        int64_t r = r0 + rslot;
+        if (r >= p.rows) r = p.rows - 1;              // surplus waves redo the last row: same values stored again
+        const TIN* wrow = wbase + r * K;
+        Raw8<TIN> raw[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (j < chn) raw[j].load(wrow + cc[j]);
+        const float upl = lwc ? p.up[r] : 0.f, lowl = lwc ? p.low[r] : 0.f;
+        const float rd = (LET && p.row_div) ? p.row_div[r] : 1.f;
+        const float rm = (LET && p.row_mul) ? p.row_mul[r] : 1.f;
+        const float inv_rd = 1.f / rd;
+        float x[CH][8];
+        float hi = -INFINITY, lo = INFINITY, dot = 0.f;
+        uint64_t nanm = 0;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (j < chn) {
+                raw[j].unpack(x[j]);
+                if constexpr (LET) {
+                    float cm[8], sh[8];
+                    Vec8<float>::load(cm_s + cc[j], cm);
+                    Vec8<float>::load(sh_s + cc[j], sh);
+                    const float lv = valid[j] ? 1.f : 0.f;     // surplus lanes must not add to w @ shift
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        dot = fmaf(x[j][i] * lv, sh[i], dot);
+                        float v = x[j][i] * cm[i];
+                        if (p.row_div) v = div_nr(v, rd, inv_rd);
+                        if (p.row_mul) v = v * rm;
+                        x[j][i] = v;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    hi = vmax(hi, x[j][i]);
+                    lo = vmin(lo, x[j][i]);
+                    nanm |= __builtin_amdgcn_fcmpf(x[j][i], x[j][i], 8);       // FCMP_UNO
+                }
+            }
+        }
+        float v4[4] = {wave_max(hi), wave_min(lo), nanm != 0 ? 1.f : 0.f, LET ? wave_sum(dot) : 0.f};
+        if (nw > 1) {
+            const int op[4] = {1, 2, 1, 0};
+            row_exchange(red, par, wid, rslot, nw, lane, v4, op);
+        }
+        hi = v4[0]; lo = v4[1];
+        const float bad = v4[2];
+        dot = v4[3];
+        if (bad != 0.f) { hi = NAN; lo = NAN; }
+        float inv_s = 0.f;
+        const QP q = make_qp(hi, lo, lwc, upl, lowl, p.nbits, p.symmetric, p.inv_q, &inv_s);
+        const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad == 0.f;     // wave-uniform
+        TOUT* yrow = ybase + r * K;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (j < chn) {
+                float yv[8];
+                if (p.nbits >= 16) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) yv[i] = x[j][i];
+                } else if (regular) {
+                    float rq[8];
+                    uint64_t susp = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float tq = x[j][i] * inv_s;
+                        rq[i] = rintf(tq);
+                        susp |= __builtin_amdgcn_fcmpf(fabsf(tq - rq[i]), fmaf(-4e-7f, fabsf(tq), 0.5f), 2);   // FCMP_OGT
+                    }
+                    if (susp != 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float tq = x[j][i] * inv_s;
+                            if (fabsf(tq - rq[i]) > fmaf(-4e-7f, fabsf(tq), 0.5f)) rq[i] = rintf(x[j][i] / q.s);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) yv[i] = (__builtin_amdgcn_fmed3f(rq[i] + q.z, 0.f, Q) - q.z) * q.s;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float v = rne_ste(x[j][i] / q.s) + q.z;
+                        v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
+                        yv[i] = (v - q.z) * q.s;
+                    }
+                }
+                Vec8<TOUT>::store(yrow + cc[j], yv);
+            }
+        }
+        if (wsub == 0) {      // every lane stores the same value (no divergent branch around the stores)
+            p.scale[r] = q.s;
+            p.zp[r] = q.z;
+            p.xmin[r] = lo;
+            p.xmax[r] = hi;
+            if (LET && p.wshift) p.wshift[r] = dot;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------
+template <typename TIN, typename TG, bool LET, int CH>
+__global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int rpb = wpb / nw;
+    const int rslot = wid / nw, wsub = wid - rslot * nw;
+    const int K = (int)p.cols;
+    const int nchunks = K >> 3;
+    const float Q = (float)((1 << p.nbits) - 1);
+    const bool need_cm = LET && p.g_col_mul, need_sh = LET && p.g_shift;
+    const bool need_row = LET && (p.g_row_div || p.g_row_mul);
+    const bool need_col = need_cm || need_sh;
+    const bool ident = p.nbits >= 16;
+    const bool need_tie = (p.gx || need_cm) && !ident;
+    const int acc_stride = chn * 512;                       // floats per accumulator slab (one wave, one vector)
+    float* cm_s = smem;
+    float* acc = smem + (LET ? K : 0);
+    float* red = acc + (need_col ? wpb * 2 * acc_stride : 0);
+    if constexpr (LET) {
+        for (int i = threadIdx.x * 4; i < K; i += blockDim.x * 4)
+            *reinterpret_cast<f32x4*>(cm_s + i) = p.col_mul ? *reinterpret_cast<const f32x4*>(p.col_mul + i) : f32x4{1.f, 1.f, 1.f, 1.f};
+        if (need_col)
+            for (int i = threadIdx.x; i < wpb * 2 * acc_stride; i += blockDim.x) acc[i] = 0.f;
+        __syncthreads();
+    }
+    float* acc_cm = acc + wid * 2 * acc_stride;             // this wave's own slabs
+    float* acc_sh = acc_cm + acc_stride;
+    bool valid[CH];
+    int cc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = (j * nw + wsub) * 64 + lane;
+        valid[j] = c < nchunks;
+        cc[j] = (valid[j] ? c : nchunks - 1) * 8;
+    }
+    const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
+    const TG* gbase = reinterpret_cast<const TG*>(p.g);
+    TG* gxbase = reinterpret_cast<TG*>(p.gx);
+    const bool lwc = p.up != nullptr;
+    int par = 0;
+    for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
+        const bool livew = r0 + rslot < p.rows;             // wave-uniform; dead waves only keep the barriers company
+        const int64_t r = livew ? r0 + rslot : p.rows - 1;
+        const TIN* wrow = wbase + r * K;
+        const TG* grow = gbase + r * K;
+        float gs = 0.f, arm = 0.f;
+        int whi = 0, wlo = 0;
+        uint32_t tieflag = 0;                               // bit j: chunk j of this wave holds an element == max or min
+        float hi = 0.f, lo = 0.f, inv_s = 0.f, rd = 1.f, rm = 1.f, gws = 0.f, inv_rd = 1.f, rmrd = 1.f;
+        QP q;
+        q.s = 1.f; q.z = 0.f; q.su = q.sl = 1.f; q.hi = q.lo = 0.f;
+        bool regular = true;
+        if (livew) {
+            Raw8<TIN> rw[CH];
+            Raw8<TG> rg[CH];
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (j < chn) { rw[j].load(wrow + cc[j]); rg[j].load(grow + cc[j]); }
+            hi = p.xmax[r];
+            lo = p.xmin[r];
+            rd = (LET && p.row_div) ? p.row_div[r] : 1.f;
+            rm = (LET && p.row_mul) ? p.row_mul[r] : 1.f;
+            gws = (LET && p.g_wshift) ? p.g_wshift[r] : 0.f;
+            inv_rd = 1.f / rd;
+            rmrd = rm * inv_rd;
+            q = make_qp(hi, lo, lwc, lwc ? p.up[r] : 0.f, lwc ? p.low[r] : 0.f, p.nbits, p.symmetric, p.inv_q, &inv_s);
+            regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f;
+            const float z = q.z;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                if (j < chn) {
+                    float w[8], G[8], gin[8];
+                    rw[j].unpack(w);
+                    rg[j].unpack(G);
+                    const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
+                    const float lv = valid[j] ? 1.f : 0.f;
+                    float cm[8], ccm[8], csh[8];
+                    if constexpr (LET) Vec8<float>::load(cm_s + cc[j], cm);
+                    uint64_t tm = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float v = w[i], a2 = w[i];
+                        if constexpr (LET) {
+                            v = v * cm[i];
+                            a2 = v;
+                            if (p.row_div) v = div_nr(v, rd, inv_rd);
+                            if (p.row_mul) v = v * rm;
+                        }
+                        const float tq = v * inv_s;
+                        const float u = (regular ? rintf(tq) : rne_ste(tq)) + z;
+                        const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
+                        const bool in = ident || qv == u;                       // inside [0, Q] (false for NaN)
+                        const float Gr = G[i] * lv;                             // surplus lanes contribute nothing
+                        gs = fmaf(Gr, (qv - z) - (in ? tq : 0.f), gs);
+                        const uint64_t mh = __builtin_amdgcn_fcmpf(v, hi, 1) & vmask;      // FCMP_OEQ
+                        const uint64_t ml = __builtin_amdgcn_fcmpf(v, lo, 1) & vmask;
+                        whi += __builtin_popcountll(mh);
+                        wlo += __builtin_popcountll(ml);
+                        tm |= mh | ml;
+                        gin[i] = in ? G[i] : 0.f;
+                        if constexpr (LET) {
+                            const float gi = in ? Gr : 0.f;
+                            if (need_row) arm = fmaf(gi, a2 * inv_rd, arm);     // b = (w*cm)/rd, x = b*rm
+                            ccm[i] = (gi * rmrd) * w[i];
+                            csh[i] = (gws * lv) * w[i];
+                        }
+                    }
+                    if constexpr (LET) {
+                        if (need_cm) slab_add(acc_cm, acc_stride / 2, j * 64 + lane, ccm);
+                        if (need_sh) slab_add(acc_sh, acc_stride / 2, j * 64 + lane, csh);
+                    }
+                    if (tm != 0) tieflag |= 1u << j;
+                    if (p.gx) Vec8<TG>::store(gxbase + r * K + cc[j], gin);    // tie chunks are rewritten below
+                }
+            }
+        }
+        float v4[4] = {wave_sum(gs), (float)whi, (float)wlo, LET ? wave_sum(arm) : 0.f};
+        if (nw > 1) {
+            const int op[4] = {0, 0, 0, 0};
+            row_exchange(red, par, wid, rslot, nw, lane, v4, op);
+        }
+        if (!livew) continue;
+        gs = ident ? 0.f : v4[0];
+        const float nhi = v4[1], nlo = v4[2];
+        arm = v4[3];
+        float ds_dhs, ds_dls;
+        if (p.symmetric) {
+            const float lvl = (float)((1 << (p.nbits - 1)) - 1);
+            const float hs = q.su * q.hi, ls = q.sl * q.lo;
+            const float a = fabsf(hs), b = fabsf(ls);
+            const float raw = fmaxf(a, b) / lvl;
+            const float pass = (raw >= 1e-5f && raw <= 1e4f) ? 1.f : 0.f;
+            const float sh = hs > 0.f ? 1.f : (hs < 0.f ? -1.f : 0.f);
+            const float sg = ls > 0.f ? 1.f : (ls < 0.f ? -1.f : 0.f);
+            const float wa = a > b ? 1.f : (a == b ? 0.5f : 0.f);
+            ds_dhs = pass * wa * sh / lvl;
+            ds_dls = pass * (1.f - wa) * sg / lvl;
+        } else {
+            ds_dhs = 1.f / Q;
+            ds_dls = -1.f / Q;
+        }
+        const float g_hs = gs * ds_dhs, g_ls = gs * ds_dls;
+        if (wsub == 0) {
+            if (p.g_up) p.g_up[r] = g_hs * q.hi * q.su * (1.f - q.su);
+            if (p.g_low) p.g_low[r] = g_ls * q.lo * q.sl * (1.f - q.sl);
+            if constexpr (LET) {
+                if (need_row) {
+                    const float tot = arm + (g_hs * q.su * q.hi + g_ls * q.sl * q.lo) / rm;
+                    if (p.g_row_mul) p.g_row_mul[r] = tot;
+                    if (p.g_row_div) p.g_row_div[r] = -rmrd * tot;
+                }
+            }
+        }
+        if (need_tie && tieflag != 0) {
+            // straight-through terms of amax / amin: only the chunks holding an element equal to the row max / min
+            const float tie_hi = g_hs * q.su / nhi, tie_lo = g_ls * q.sl / nlo;
+            const float z = q.z;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                if (j < chn && ((tieflag >> j) & 1u)) {
+                    float w[8], G[8], gin[8], ccm[8];
+                    Vec8<TIN>::load(wrow + cc[j], w);
+                    Vec8<TG>::load(grow + cc[j], G);
+                    float cm[8];
+                    if constexpr (LET) Vec8<float>::load(cm_s + cc[j], cm);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float v = w[i];
+                        if constexpr (LET) {
+                            v = v * cm[i];
+                            if (p.row_div) v = div_nr(v, rd, inv_rd);
+                            if (p.row_mul) v = v * rm;
+                        }
+                        const float tq = v * inv_s;
+                        const float u = (regular ? rintf(tq) : rne_ste(tq)) + z;
+                        const bool in = __builtin_amdgcn_fmed3f(u, 0.f, Q) == u;
+                        float tt = 0.f;
+                        if (v == hi) tt += tie_hi;
+                        if (v == lo) tt += tie_lo;
+                        gin[i] = (in ? G[i] : 0.f) + tt;
+                        ccm[i] = valid[j] ? (tt * rmrd) * w[i] : 0.f;
+                    }
+                    if constexpr (LET) {
+                        if (need_cm) slab_add(acc_cm, acc_stride / 2, j * 64 + lane, ccm);
+                    }
+                    if (p.gx) Vec8<TG>::store(gxbase + r * K + cc[j], gin);
+                }
+            }
+        }
+    }
+    if constexpr (LET) {
+        if (need_col) {
+            // sum the workgroup's slabs in wave order and write ONE partial row per workgroup (colreduce_kernel finishes)
+            __syncthreads();
+            float* wcm = p.ws + (int64_t)blockIdx.x * K;
+            float* wsh = p.ws + ((int64_t)gridDim.x + blockIdx.x) * K;
+            for (int e = threadIdx.x; e < K; e += blockDim.x) {
+                const int c = e >> 3, i = e & 7;
+                const int qd = c >> 6, ln = c & 63;
+                const int ws_ = qd % nw, j = qd / nw;
+                const int slot = (i >> 2) * (acc_stride / 2) + (j * 64 + ln) * 4 + (i & 3);    // [plane][chunk slot][4]
+                float s0 = 0.f, s1 = 0.f;
+                for (int rs = 0; rs < rpb; ++rs) {
+                    const float* a = acc + (rs * nw + ws_) * 2 * acc_stride;
+                    s0 += a[slot];
+                    s1 += a[acc_stride + slot];
+                }
+                if (p.g_col_mul) wcm[e] = s0;
+                if (p.g_shift) wsh[e] = s1;
+            }
+        }
+    }
+}
+
+// dynamic LDS above 64 KiB has to be granted per kernel; remembered so that the attribute call happens once per size
+int set_smem(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return OQ_OK;
+    static const void* seen_k[64];
+    static size_t seen_b[64];
+    static int n_seen = 0;
+    for (int i = 0; i < n_seen; ++i)
+        if (seen_k[i] == kernel && seen_b[i] >= bytes) return OQ_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return OQ_E_LAUNCH;
+    if (n_seen < 64) { seen_k[n_seen] = kernel; seen_b[n_seen] = bytes; ++n_seen; }
+    return OQ_OK;
+}
+
+int n_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+constexpr size_t LDS_BUDGET = 156 * 1024;
+
+size_t bwd_smem(const FQ& p, const RowGeo& g, bool let) {
+    const bool need_col = let && (p.g_col_mul || p.g_shift);
+    return sizeof(float) * ((let ? p.cols : 0) + (need_col ? (size_t)g.wpb * 2 * g.chn * 512 : 0) + 64);
+}
+
+bool bwd_geo(const FQ& p, bool let, RowGeo* g) {
+    // column accumulators live in LDS: spread the row over more waves until the slabs fit
+    if (!row_geo(p.cols, (int)env_i("OQ_ROWQ_BWD_NW", 0), g)) return false;
+    while (bwd_smem(p, *g, let) > LDS_BUDGET) {
+        if (g->nw >= 8 || !row_geo(p.cols, g->nw * 2, g)) return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+#define RQ_FWD(TIN, TOUT)                                                                                                       \
+    do {                                                                                                                        \
+        if (let) {                                                                                                              \
+            if (g.chn <= 4) { rc = set_smem((const void*)rowq_fwd_kernel<TIN, TOUT, true, 4>, smem); hipLaunchKernelGGL((rowq_fwd_kernel<TIN, TOUT, true, 4>), grid, blk, smem, st, p, g.nw, g.chn); }    \
+            else { rc = set_smem((const void*)rowq_fwd_kernel<TIN, TOUT, true, 8>, smem); hipLaunchKernelGGL((rowq_fwd_kernel<TIN, TOUT, true, 8>), grid, blk, smem, st, p, g.nw, g.chn); }              \
+        } else {                                                                                                                \
+            if (g.chn <= 4) hipLaunchKernelGGL((rowq_fwd_kernel<TIN, TOUT, false, 4>), grid, blk, smem, st, p, g.nw, g.chn);    \
+            else hipLaunchKernelGGL((rowq_fwd_kernel<TIN, TOUT, false, 8>), grid, blk, smem, st, p, g.nw, g.chn);               \
+        }                                                                                                                       \
+    } while (0)
+
+int oq_rowq_fwd(const FQ& p, int w_dtype, int y_dtype, void* stream) {
+    if (p.seg != p.cols || env_i("OQ_ROWQ", 1) == 0) return 1;
+    RowGeo g;
+    if (!row_geo(p.cols, (int)env_i("OQ_ROWQ_FWD_NW", 0), &g)) return 1;
+    const bool let = p.col_mul || p.row_div || p.row_mul || p.shift;
+    if (let && env_i("OQ_ROWQ_FWD_LET", 1) == 0) return 1;
+    const size_t smem = sizeof(float) * ((let ? 2 * p.cols : 0) + 64);
+    if (smem > LDS_BUDGET) return 1;
+    const int rpb = g.wpb / g.nw;
+    const int64_t need = (p.rows + rpb - 1) / rpb;
+    const int64_t cap = (int64_t)n_cus() * env_i("OQ_ROWQ_FWD_WGS", 8);
+    const dim3 grid((unsigned)(need < cap ? need : cap)), blk((unsigned)(g.wpb * 64));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = OQ_OK;
+    switch (w_dtype * 3 + y_dtype) {
+        case OQ_F32 * 3 + OQ_F32: RQ_FWD(float, float); break;
+        case OQ_F32 * 3 + OQ_BF16: RQ_FWD(float, bf16_t); break;
+        case OQ_F16 * 3 + OQ_F32: RQ_FWD(f16_t, float); break;
+        case OQ_F16 * 3 + OQ_BF16: RQ_FWD(f16_t, bf16_t); break;
+        case OQ_BF16 * 3 + OQ_BF16: RQ_FWD(bf16_t, bf16_t); break;
+        default: return 1;
+    }
+    if (rc) {
+        oq_set_error("oq_fakequant_fwd(rowq): cannot reserve %zu bytes of LDS", smem);
+        return rc;
+    }
+    OQ_CHECK_LAUNCH("oq_fakequant_fwd(rowq)");
+    return OQ_OK;
+}
+
+#define RQ_BWD(TIN, TG)                                                                                                         \
+    do {                                                                                                                        \
+        if (let) {                                                                                                              \
+            if (g.chn <= 4) { rc = set_smem((const void*)rowq_bwd_kernel<TIN, TG, true, 4>, smem); hipLaunchKernelGGL((rowq_bwd_kernel<TIN, TG, true, 4>), grid, blk, smem, st, p, g.nw, g.chn); }        \
+            else { rc = set_smem((const void*)rowq_bwd_kernel<TIN, TG, true, 8>, smem); hipLaunchKernelGGL((rowq_bwd_kernel<TIN, TG, true, 8>), grid, blk, smem, st, p, g.nw, g.chn); }                  \
+        } else {                                                                                                                \
+            if (g.chn <= 4) hipLaunchKernelGGL((rowq_bwd_kernel<TIN, TG, false, 4>), grid, blk, smem, st, p, g.nw, g.chn);      \
+            else hipLaunchKernelGGL((rowq_bwd_kernel<TIN, TG, false, 8>), grid, blk, smem, st, p, g.nw, g.chn);                 \
+        }                                                                                                                       \
+    } while (0)
+
+static int64_t bwd_grid(const FQ& p, const RowGeo& g, bool let) {
+    const int rpb = g.wpb / g.nw;
+    const int64_t need = (p.rows + rpb - 1) / rpb;
+    const size_t smem = bwd_smem(p, g, let);
+    int64_t per_cu = (int64_t)((160 * 1024) / (smem > 1024 ? smem : 1024));
+    const int64_t mx = env_i("OQ_ROWQ_BWD_WGS", 8);
+    if (per_cu > mx) per_cu = mx;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t cap = (int64_t)n_cus() * per_cu;
+    return need < cap ? need : cap;
+}
+
+int64_t oq_rowq_bwd_blocks(int64_t rows, int64_t cols) {
+    // upper bound on the workgroups of a LET backward with column gradients (the workspace has 2 rows per workgroup)
+    FQ p{};
+    p.rows = rows; p.cols = cols; p.seg = cols;
+    float dummy = 0.f;
+    p.g_col_mul = &dummy; p.g_shift = &dummy;
+    RowGeo g;
+    if (env_i("OQ_ROWQ", 1) == 0 || !bwd_geo(p, true, &g)) return 0;
+    return bwd_grid(p, g, true);
+}
+
+int oq_rowq_bwd(const FQ& pin, int w_dtype, int g_dtype, float* workspace, int64_t workspace_floats, int64_t* partial_rows,
+                void* stream) {
+    if (pin.seg != pin.cols || env_i("OQ_ROWQ", 1) == 0) return 1;
+    FQ p = pin;
+    const bool let = p.col_mul || p.row_div || p.row_mul || p.g_col_mul || p.g_shift || p.g_row_div || p.g_row_mul;
+    if (let && env_i("OQ_ROWQ_BWD_LET", 1) == 0) return 1;
+    RowGeo g;
+    if (!bwd_geo(p, let, &g)) return 1;
+    const size_t smem = bwd_smem(p, g, let);
+    const int64_t nblk = bwd_grid(p, g, let);
+    *partial_rows = 0;
+    if (p.g_col_mul || p.g_shift) {
+        OQ_CHECK_ARG(workspace && workspace_floats >= 2 * nblk * p.cols,
+                     "oq_fakequant_bwd: workspace of %lld floats needed (oq_fakequant_bwd_workspace)", (long long)(2 * nblk * p.cols));
+        p.ws = workspace;
+        *partial_rows = nblk;
+    }
+    const dim3 grid((unsigned)nblk), blk((unsigned)(g.wpb * 64));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = OQ_OK;
+    switch (w_dtype * 3 + g_dtype) {
+        case OQ_F32 * 3 + OQ_F32: RQ_BWD(float, float); break;
+        case OQ_F32 * 3 + OQ_BF16: RQ_BWD(float, bf16_t); break;
+        case OQ_F16 * 3 + OQ_F32: RQ_BWD(f16_t, float); break;
+        case OQ_F16 * 3 + OQ_BF16: RQ_BWD(f16_t, bf16_t); break;
+        case OQ_BF16 * 3 + OQ_BF16: RQ_BWD(bf16_t, bf16_t); break;
+        default: return 1;
+    }
+    if (rc) {
+        oq_set_error("oq_fakequant_bwd(rowq): cannot reserve %zu bytes of LDS", smem);
+        return rc;
+    }
+    OQ_CHECK_LAUNCH("oq_fakequant_bwd(rowq)");
+    return OQ_OK;
+}

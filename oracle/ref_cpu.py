@@ -157,9 +157,11 @@ class _GradRoundSTE(torch.autograd.Function):
 
 class _FusedAttnModel(torch.autograd.Function):
     """Storage model of the product path's fused causal attention (omniquant_amd/csrc/oq_attn.hip), fp32 arithmetic:
-    forward  P = softmax(scale * q k^T + mask) in fp32, rounded to `dtype` only as the operand of P @ v;
-    backward as the kernel does it: dV = P_r^T dO, dP = dO v^T, D = rowsum(dO * O_r) with the STORED (rounded) output,
-    dS = P * (dP - D) rounded to `dtype` (the kernel stores dS^T in bf16), dQ = scale * dS k, dK = scale * dS^T q.
+    forward  p~ = exp(s - rowmax), l = sum p~ (fp32); the operand of the P @ v product is p~ rounded to `dtype`
+             (un-normalised, as the kernel's online softmax feeds its MFMA), O = (p~_r @ v) / l, stored in `dtype`;
+    backward as the kernel does it: P = softmax (fp32, recomputed), dV = P_r^T dO with P rounded, dP = dO v^T,
+             D = rowsum(dO * O_r) with the STORED output, dS = scale * P * (dP - D) rounded to `dtype` (the kernel keeps
+             dS^T in bf16 for both dK and the dQ GEMM), dQ = dS k, dK = dS^T q.
     The mathematics is that of models/int_llama_layer.py:143-163; only the rounding points are the kernel's."""
 
     @staticmethod
@@ -167,25 +169,26 @@ class _FusedAttnModel(torch.autograd.Function):
         s = torch.matmul(q, k.transpose(2, 3)) * scale
         if mask is not None:
             s = torch.max(s + mask, torch.tensor(torch.finfo(s.dtype).min))
-        p = torch.softmax(s, dim=-1)
-        pr = p.to(dtype).to(p.dtype)
-        o = torch.matmul(pr, v)
+        pt = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        l = pt.sum(dim=-1, keepdim=True)
+        o = torch.matmul(pt.to(dtype).to(pt.dtype), v) / l
         orr = o.to(dtype).to(o.dtype)
-        ctx.save_for_backward(q, k, v, p, pr, orr)
+        p = pt / l
+        ctx.save_for_backward(q, k, v, p, orr)
         ctx.scale, ctx.dtype = scale, dtype
         return orr
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v, p, pr, orr = ctx.saved_tensors
+        q, k, v, p, orr = ctx.saved_tensors
         dt = ctx.dtype
         go = go.to(dt).to(go.dtype)
-        dv = torch.matmul(pr.transpose(2, 3), go)
+        dv = torch.matmul(p.to(dt).to(p.dtype).transpose(2, 3), go)
         dp = torch.matmul(go, v.transpose(2, 3))
         d = (go * orr).sum(-1, keepdim=True)
-        ds = (p * (dp - d)).to(dt).to(p.dtype)
-        dq = torch.matmul(ds, k) * ctx.scale
-        dk = torch.matmul(ds.transpose(2, 3), q) * ctx.scale
+        ds = (p * (dp - d) * ctx.scale).to(dt).to(p.dtype)
+        dq = torch.matmul(ds, k)
+        dk = torch.matmul(ds.transpose(2, 3), q)
         return dq, dk, dv, None, None, None
 
 
