@@ -39,7 +39,9 @@ struct RowGeo {
 bool row_geo(int64_t cols, int force_nw, RowGeo* g) {
     if (cols % 8 != 0 || cols < 512 || cols > 32768) return false;
     const int64_t chunks = cols / 8;
-    int nw = force_nw > 0 ? force_nw : 1;
+    // two waves per row by default (4 chunks per lane, ~110 VGPRs, 4 waves per SIMD): measured better than one wave with 8
+    // chunks (175 VGPRs) on every 4096-wide kernel of the step, in-step 254.8 -> 259 sample-steps/s (tools/sweep_rowq.sh)
+    int nw = force_nw > 0 ? force_nw : (chunks >= 128 ? 2 : 1);
     while (nw <= 8 && (chunks + 64 * nw - 1) / (64 * nw) > 8) nw <<= 1;
     if (nw > 8 || (nw & (nw - 1))) return false;
     g->nw = nw;
@@ -558,7 +560,9 @@ int oq_rowq_bwd(const FQ& pin, int w_dtype, int g_dtype, float* workspace, int64
     if (pin.seg != pin.cols || env_i("OQ_ROWQ", 1) == 0) return 1;
     FQ p = pin;
     const bool let = p.col_mul || p.row_div || p.row_mul || p.g_col_mul || p.g_shift || p.g_row_div || p.g_row_mul;
-    if (let && env_i("OQ_ROWQ_BWD_LET", 1) == 0) return 1;
+    // LET backward (column gradients): the segment kernel's register accumulators win (46 us vs 61 us with the LDS slabs
+    // on a 4096 x 4096 weight, same box); the slab variant stays available for A/B
+    if (let && env_i("OQ_ROWQ_BWD_LET", 0) == 0) return 1;
     RowGeo g;
     if (!bwd_geo(p, let, &g)) return 1;
     const size_t smem = bwd_smem(p, g, let);
