@@ -438,6 +438,375 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LET weights (col_mul / row_div / row_mul / shift + their gradients): row-GROUP kernels
+// ---------------------------------------------------------------------------------------------------
+// A workgroup of 4 waves walks groups of 4 rows.  Lane -> column ownership is fixed (wave w, lane l own the chunks
+// (j*4 + w)*64 + l), so col_mul / shift sit in registers and the column gradients accumulate in registers across all
+// rows of the workgroup (written once, as one partial row per workgroup, at the end).  What the segment kernels pay per
+// ROW and per WAVE -- the sigmoids, scale / zero-point, the reductions' tail and two barriers -- is paid once per row:
+// wave w finalises row w of the group, the others read the result from LDS; 2 (forward) / 3 (backward) barriers per
+// FOUR rows.  All 4 rows' loads are in flight together (8-16 KB per wave).
+constexpr int RG = 4;
+#ifndef LETQ_FWD_WPE
+#define LETQ_FWD_WPE 3      // min waves per SIMD the register allocator must leave room for
+#endif
+#ifndef LETQ_BWD_WPE
+#define LETQ_BWD_WPE 3
+#endif
+
+struct RowQ {       // per-row constants handed from the finalising wave to everybody (one LDS broadcast read each)
+    float s, z, inv_s, regular, hi, lo, rd, rm, inv_rd, rmrd, gws, live;
+};
+
+template <typename TIN, typename TOUT, int CH>
+__global__ void __launch_bounds__(256, CH <= 2 ? LETQ_FWD_WPE : 2) letq_fwd_kernel(FQ p) {
+    __shared__ __attribute__((aligned(16))) float part[4][RG][4];
+    __shared__ __attribute__((aligned(16))) float qps[RG][4];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = (int)p.cols;
+    const int nchunks = K >> 3;
+    const float Q = (float)((1 << p.nbits) - 1);
+    bool valid[CH];
+    int cc[CH];
+    float cm[CH][8], sh[CH][8];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = (j * 4 + wid) * 64 + lane;
+        valid[j] = c < nchunks;
+        cc[j] = (valid[j] ? c : nchunks - 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { cm[j][i] = 1.f; sh[j][i] = 0.f; }
+        if (p.col_mul) Vec8<float>::load(p.col_mul + cc[j], cm[j]);
+        if (p.shift && valid[j]) Vec8<float>::load(p.shift + cc[j], sh[j]);      // surplus lanes add nothing to w @ shift
+    }
+    const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
+    TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
+    const bool lwc = p.up != nullptr;
+    const bool has_rd = p.row_div != nullptr, has_rm = p.row_mul != nullptr;
+    const int64_t ngroups = (p.rows + RG - 1) / RG;
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const int64_t r0 = g * RG;
+        // ---- phase A: load + transform this wave's columns of the 4 rows, per-row partial min / max / NaN / w@shift ----
+        Raw8<TIN> raw[RG][CH];
+        int64_t rows_[RG];
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            rows_[rr] = r0 + rr < p.rows ? r0 + rr : p.rows - 1;      // a short last group redoes the last row (same values)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) raw[rr][j].load(wbase + rows_[rr] * K + cc[j]);
+        }
+        float x[RG][CH][8];
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const float rd = has_rd ? p.row_div[rows_[rr]] : 1.f;
+            const float rm = has_rm ? p.row_mul[rows_[rr]] : 1.f;
+            const float inv_rd = 1.f / rd;
+            float hi = -INFINITY, lo = INFINITY, dot = 0.f;
+            uint64_t nanm = 0;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                raw[rr][j].unpack(x[rr][j]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    dot = fmaf(x[rr][j][i], sh[j][i], dot);
+                    float v = x[rr][j][i] * cm[j][i];
+                    if (has_rd) v = div_nr(v, rd, inv_rd);
+                    if (has_rm) v = v * rm;
+                    x[rr][j][i] = v;
+                    hi = vmax(hi, v);
+                    lo = vmin(lo, v);
+                    nanm |= __builtin_amdgcn_fcmpf(v, v, 8);       // FCMP_UNO
+                }
+            }
+            hi = wave_max(hi);
+            lo = wave_min(lo);
+            dot = wave_sum(dot);
+            if (lane == 0) *reinterpret_cast<f32x4*>(&part[wid][rr][0]) = f32x4{hi, lo, nanm != 0 ? 1.f : 0.f, dot};
+        }
+        __syncthreads();
+        // ---- phase B: wave w finalises row w ------------------------------------------------------------------------
+        {
+            const int rr = wid;
+            float hi = -INFINITY, lo = INFINITY, bad = 0.f, dot = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(&part[w2][rr][0]);
+                hi = fmaxf(hi, q4[0]); lo = fminf(lo, q4[1]); bad = fmaxf(bad, q4[2]); dot += q4[3];
+            }
+            if (bad != 0.f) { hi = NAN; lo = NAN; }
+            const int64_t r = r0 + rr < p.rows ? r0 + rr : p.rows - 1;
+            float inv_s = 0.f;
+            const QP q = make_qp(hi, lo, lwc, lwc ? p.up[r] : 0.f, lwc ? p.low[r] : 0.f, p.nbits, p.symmetric, p.inv_q, &inv_s);
+            const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad == 0.f;
+            p.scale[r] = q.s;          // every lane stores the same value
+            p.zp[r] = q.z;
+            p.xmin[r] = lo;
+            p.xmax[r] = hi;
+            if (p.wshift) p.wshift[r] = dot;
+            if (lane == 0) *reinterpret_cast<f32x4*>(&qps[rr][0]) = f32x4{q.s, q.z, inv_s, regular ? 1.f : 0.f};
+        }
+        __syncthreads();
+        // ---- phase C: quantise and store ------------------------------------------------------------------------------
+#pragma unroll
+        for (int rr = 0; rr < RG; ++rr) {
+            const f32x4 q4 = *reinterpret_cast<const f32x4*>(&qps[rr][0]);
+            const float qs = q4[0], qz = q4[1], inv_s = q4[2];
+            const bool regular = q4[3] != 0.f;
+            TOUT* yrow = ybase + rows_[rr] * K;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                float yv[8];
+                if (p.nbits >= 16) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) yv[i] = x[rr][j][i];
+                } else if (regular) {
+                    float rq[8];
+                    uint64_t susp = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float tq = x[rr][j][i] * inv_s;
+                        rq[i] = rintf(tq);
+                        susp |= __builtin_amdgcn_fcmpf(fabsf(tq - rq[i]), fmaf(-4e-7f, fabsf(tq), 0.5f), 2);   // FCMP_OGT
+                    }
+                    if (susp != 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float tq = x[rr][j][i] * inv_s;
+                            if (fabsf(tq - rq[i]) > fmaf(-4e-7f, fabsf(tq), 0.5f)) rq[i] = rintf(x[rr][j][i] / qs);
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) yv[i] = (__builtin_amdgcn_fmed3f(rq[i] + qz, 0.f, Q) - qz) * qs;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float v = rne_ste(x[rr][j][i] / qs) + qz;
+                        v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
+                        yv[i] = (v - qz) * qs;
+                    }
+                }
+                Vec8<TOUT>::store(yrow + cc[j], yv);
+            }
+        }
+    }
+}
+
+template <typename TIN, typename TG, int CH>
+__global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kernel(FQ p) {
+    __shared__ __attribute__((aligned(16))) float part[4][RG][4];
+    __shared__ __attribute__((aligned(16))) float qps2[2][RG][12];    // by group parity: phase A of the next group overlaps phase D
+    __shared__ __attribute__((aligned(16))) float ties[RG][4];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = (int)p.cols;
+    const int nchunks = K >> 3;
+    const float Q = (float)((1 << p.nbits) - 1);
+    const bool need_cm = p.g_col_mul != nullptr, need_sh = p.g_shift != nullptr;
+    const bool need_row = p.g_row_div || p.g_row_mul;
+    const bool ident = p.nbits >= 16;
+    const bool has_rd = p.row_div != nullptr, has_rm = p.row_mul != nullptr;
+    bool valid[CH];
+    int cc[CH];
+    float cm[CH][8], acc_cm[CH][8], acc_sh[CH][8];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = (j * 4 + wid) * 64 + lane;
+        valid[j] = c < nchunks;
+        cc[j] = (valid[j] ? c : nchunks - 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { cm[j][i] = 1.f; acc_cm[j][i] = 0.f; acc_sh[j][i] = 0.f; }
+        if (p.col_mul) Vec8<float>::load(p.col_mul + cc[j], cm[j]);
+    }
+    const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
+    const TG* gbase = reinterpret_cast<const TG*>(p.g);
+    const bool lwc = p.up != nullptr;
+    const int64_t ngroups = (p.rows + RG - 1) / RG;
+    int par = 0;
+    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x, par ^= 1) {
+        const int64_t r0 = g * RG;
+        float (*qps)[12] = qps2[par];
+        auto row_of = [&](int rr) { return r0 + rr < p.rows ? r0 + rr : p.rows - 1; };
+        // the first row's chunks are in flight under phase A; inside phase B row rr+1 is loaded while row rr is processed
+        // (two rows of raw vectors live at a time: keeps the kernel near 128 VGPRs instead of 300)
+        Raw8<TIN> cw[CH];
+        Raw8<TG> cg[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            cw[j].load(wbase + row_of(0) * K + cc[j]);
+            cg[j].load(gbase + row_of(0) * K + cc[j]);
+        }
+        // ---- phase A: wave w prepares the constants of row w ---------------------------------------------------------
+        QP q;                       // kept by the finalising wave for phase C
+        float my_rm = 1.f, my_rmrd = 1.f;
+        {
+            const int64_t r = row_of(wid);
+            const float hi = p.xmax[r], lo = p.xmin[r];
+            const float rd = has_rd ? p.row_div[r] : 1.f;
+            const float rm = has_rm ? p.row_mul[r] : 1.f;
+            const float gws = p.g_wshift ? p.g_wshift[r] : 0.f;
+            const float inv_rd = 1.f / rd;
+            float inv_s = 0.f;
+            q = make_qp(hi, lo, lwc, lwc ? p.up[r] : 0.f, lwc ? p.low[r] : 0.f, p.nbits, p.symmetric, p.inv_q, &inv_s);
+            const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f;
+            my_rm = rm;
+            my_rmrd = rm * inv_rd;
+            if (lane == 0) {
+                float* d = &qps[wid][0];
+                *reinterpret_cast<f32x4*>(d) = f32x4{q.s, q.z, inv_s, regular ? 1.f : 0.f};
+                *reinterpret_cast<f32x4*>(d + 4) = f32x4{hi, lo, rd, rm};
+                *reinterpret_cast<f32x4*>(d + 8) = f32x4{inv_rd, rm * inv_rd, gws, r0 + wid < p.rows ? 1.f : 0.f};
+            }
+        }
+        __syncthreads();
+        // ---- phase B: element pass over this wave's columns of the 4 rows --------------------------------------------
+        uint32_t tieflag = 0;               // bit rr*CH + j
+#pragma unroll 1                            // a real loop: unrolled, the four rows' constants and vectors cost 260+ VGPRs
+        for (int rr = 0; rr < RG; ++rr) {
+            const f32x4 qa = *reinterpret_cast<const f32x4*>(&qps[rr][0]);
+            const f32x4 qb = *reinterpret_cast<const f32x4*>(&qps[rr][4]);
+            const f32x4 qc = *reinterpret_cast<const f32x4*>(&qps[rr][8]);
+            const float z = qa[1], inv_s = qa[2], hi = qb[0], lo = qb[1], rd = qb[2], rm = qb[3];
+            const float inv_rd = qc[0], rmrd = qc[1], gws = qc[2] * qc[3], rowlive = qc[3];
+            const bool regular = qa[3] != 0.f;
+            float gs = 0.f, arm = 0.f;
+            int whi = 0, wlo = 0;
+            Raw8<TIN> nw_[CH];
+            Raw8<TG> ng_[CH];
+            if (rr + 1 < RG) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    nw_[j].load(wbase + row_of(rr + 1) * K + cc[j]);
+                    ng_[j].load(gbase + row_of(rr + 1) * K + cc[j]);
+                }
+            }
+            // (a separate select-free copy of this loop for the regular case was tried: it pushed the kernel over 168 VGPRs,
+            //  spilled, and ran 25 % slower)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                float w[8], G[8];
+                cw[j].unpack(w);
+                cg[j].unpack(G);
+                const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
+                const float lv = valid[j] ? rowlive : 0.f;         // surplus lanes / rows of a short last group add nothing
+                uint64_t tm = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = w[i] * cm[j][i];
+                    const float a2 = v;
+                    if (has_rd) v = div_nr(v, rd, inv_rd);
+                    if (has_rm) v = v * rm;
+                    const float tq = v * inv_s;
+                    const float u = (regular ? rintf(tq) : rne_ste(tq)) + z;
+                    const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
+                    const bool in = ident || qv == u;
+                    const float Gr = G[i] * lv;
+                    gs = fmaf(Gr, (qv - z) - (in ? tq : 0.f), gs);
+                    const uint64_t mh = __builtin_amdgcn_fcmpf(v, hi, 1) & vmask;      // FCMP_OEQ
+                    const uint64_t ml = __builtin_amdgcn_fcmpf(v, lo, 1) & vmask;
+                    whi += __builtin_popcountll(mh);
+                    wlo += __builtin_popcountll(ml);
+                    tm |= mh | ml;
+                    const float gi = in ? Gr : 0.f;
+                    if (need_row) arm = fmaf(gi, a2 * inv_rd, arm);
+                    if (need_cm) acc_cm[j][i] = fmaf(gi * rmrd, w[i], acc_cm[j][i]);
+                    if (need_sh) acc_sh[j][i] = fmaf(gws * (valid[j] ? 1.f : 0.f), w[i], acc_sh[j][i]);
+                }
+                if (tm != 0) tieflag |= 1u << (rr * CH + j);
+            }
+            gs = wave_sum(gs);
+            arm = wave_sum(arm);
+            if (lane == 0) *reinterpret_cast<f32x4*>(&part[wid][rr][0]) = f32x4{gs, (float)whi, (float)wlo, arm};
+            if (rr + 1 < RG) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) { cw[j] = nw_[j]; cg[j] = ng_[j]; }
+            }
+        }
+        __syncthreads();
+        // ---- phase C: wave w finalises row w --------------------------------------------------------------------------
+        {
+            float gs = 0.f, nhi = 0.f, nlo = 0.f, arm = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(&part[w2][wid][0]);
+                gs += q4[0]; nhi += q4[1]; nlo += q4[2]; arm += q4[3];
+            }
+            if (ident) gs = 0.f;
+            float ds_dhs, ds_dls;
+            if (p.symmetric) {
+                const float lvl = (float)((1 << (p.nbits - 1)) - 1);
+                const float hs = q.su * q.hi, ls = q.sl * q.lo;
+                const float a = fabsf(hs), b = fabsf(ls);
+                const float raw = fmaxf(a, b) / lvl;
+                const float pass = (raw >= 1e-5f && raw <= 1e4f) ? 1.f : 0.f;
+                const float sh_ = hs > 0.f ? 1.f : (hs < 0.f ? -1.f : 0.f);
+                const float sg = ls > 0.f ? 1.f : (ls < 0.f ? -1.f : 0.f);
+                const float wa = a > b ? 1.f : (a == b ? 0.5f : 0.f);
+                ds_dhs = pass * wa * sh_ / lvl;
+                ds_dls = pass * (1.f - wa) * sg / lvl;
+            } else {
+                ds_dhs = 1.f / Q;
+                ds_dls = -1.f / Q;
+            }
+            const float g_hs = gs * ds_dhs, g_ls = gs * ds_dls;
+            if (r0 + wid < p.rows) {
+                const int64_t r = r0 + wid;
+                if (p.g_up) p.g_up[r] = g_hs * q.hi * q.su * (1.f - q.su);
+                if (p.g_low) p.g_low[r] = g_ls * q.lo * q.sl * (1.f - q.sl);
+                if (need_row) {
+                    const float tot = arm + (g_hs * q.su * q.hi + g_ls * q.sl * q.lo) / my_rm;
+                    if (p.g_row_mul) p.g_row_mul[r] = tot;
+                    if (p.g_row_div) p.g_row_div[r] = -my_rmrd * tot;
+                }
+            }
+            if (lane == 0) *reinterpret_cast<f32x4*>(&ties[wid][0]) =
+                f32x4{ident ? 0.f : g_hs * q.su / nhi, ident ? 0.f : g_ls * q.sl / nlo, 0.f, 0.f};
+        }
+        __syncthreads();
+        // ---- phase D: straight-through terms of amax / amin for the chunks that hold such an element ------------------
+        if (need_cm && tieflag != 0) {
+#pragma unroll 1
+            for (int rr = 0; rr < RG; ++rr) {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    if ((tieflag >> (rr * CH + j)) & 1u) {
+                        const f32x4 qb = *reinterpret_cast<const f32x4*>(&qps[rr][4]);
+                        const f32x4 qc = *reinterpret_cast<const f32x4*>(&qps[rr][8]);
+                        const f32x4 tt4 = *reinterpret_cast<const f32x4*>(&ties[rr][0]);
+                        const float hi = qb[0], lo = qb[1], rd = qb[2], rm = qb[3], inv_rd = qc[0], rmrd = qc[1];
+                        const float lv = valid[j] ? qc[3] : 0.f;
+                        float w[8];
+                        Vec8<TIN>::load(wbase + row_of(rr) * K + cc[j], w);      // rare: reloaded (cache hit), not kept
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            float v = w[i] * cm[j][i];
+                            if (has_rd) v = div_nr(v, rd, inv_rd);
+                            if (has_rm) v = v * rm;
+                            float tt = 0.f;
+                            if (v == hi) tt += tt4[0];
+                            if (v == lo) tt += tt4[1];
+                            acc_cm[j][i] = fmaf((tt * lv) * rmrd, w[i], acc_cm[j][i]);
+                        }
+                    }
+                }
+            }
+        }
+        // (the next group writes the OTHER qps buffer; `part` and `ties` are rewritten only behind the next group's barriers)
+    }
+    if (need_cm || need_sh) {
+        float* wcm = p.ws + (int64_t)blockIdx.x * K;
+        float* wsh = p.ws + ((int64_t)gridDim.x + blockIdx.x) * K;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (valid[j]) {
+                if (need_cm) Vec8<float>::store(wcm + cc[j], acc_cm[j]);
+                if (need_sh) Vec8<float>::store(wsh + cc[j], acc_sh[j]);
+            }
+        }
+    }
+}
+
 // dynamic LDS above 64 KiB has to be granted per kernel; remembered so that the attribute call happens once per size
 int set_smem(const void* kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return OQ_OK;
@@ -491,11 +860,52 @@ bool bwd_geo(const FQ& p, bool let, RowGeo* g) {
         }                                                                                                                       \
     } while (0)
 
+// row-group LET kernels: rows of 2048 .. 6144 elements (CH = 2 or 3 chunks per lane with 4 waves per row)
+static int letq_ch(int64_t cols) {
+    if (cols % 8 != 0 || env_i("OQ_LETQ", 1) == 0) return 0;
+    const int64_t chunks = cols / 8;
+    if (chunks > 256 && chunks <= 512) return 2;
+    if (chunks > 512 && chunks <= 768) return 3;
+    return 0;
+}
+
+#define LQ_FWD(TIN, TOUT)                                                                                    \
+    do {                                                                                                     \
+        if (ch == 2) hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 2>), grid, dim3(256), 0, st, p);         \
+        else hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 3>), grid, dim3(256), 0, st, p);                 \
+    } while (0)
+#define LQ_BWD(TIN, TG)                                                                                      \
+    do {                                                                                                     \
+        if (ch == 2) hipLaunchKernelGGL((letq_bwd_kernel<TIN, TG, 2>), grid, dim3(256), 0, st, p);           \
+        else hipLaunchKernelGGL((letq_bwd_kernel<TIN, TG, 3>), grid, dim3(256), 0, st, p);                   \
+    } while (0)
+
+static int letq_fwd(const FQ& p, int ch, int w_dtype, int y_dtype, void* stream) {
+    const int64_t ngroups = (p.rows + RG - 1) / RG;
+    const int64_t cap = (int64_t)n_cus() * env_i("OQ_LETQ_FWD_WGS", 8);
+    const dim3 grid((unsigned)(ngroups < cap ? ngroups : cap));
+    hipStream_t st = (hipStream_t)stream;
+    switch (w_dtype * 3 + y_dtype) {
+        case OQ_F32 * 3 + OQ_F32: LQ_FWD(float, float); break;
+        case OQ_F32 * 3 + OQ_BF16: LQ_FWD(float, bf16_t); break;
+        case OQ_F16 * 3 + OQ_F32: LQ_FWD(f16_t, float); break;
+        case OQ_F16 * 3 + OQ_BF16: LQ_FWD(f16_t, bf16_t); break;
+        case OQ_BF16 * 3 + OQ_BF16: LQ_FWD(bf16_t, bf16_t); break;
+        default: return 1;
+    }
+    OQ_CHECK_LAUNCH("oq_fakequant_fwd(letq)");
+    return OQ_OK;
+}
+
 int oq_rowq_fwd(const FQ& p, int w_dtype, int y_dtype, void* stream) {
     if (p.seg != p.cols || env_i("OQ_ROWQ", 1) == 0) return 1;
+    const bool let = p.col_mul || p.row_div || p.row_mul || p.shift;
+    if (let) {
+        const int ch = letq_ch(p.cols);
+        if (ch) return letq_fwd(p, ch, w_dtype, y_dtype, stream);
+    }
     RowGeo g;
     if (!row_geo(p.cols, (int)env_i("OQ_ROWQ_FWD_NW", 0), &g)) return 1;
-    const bool let = p.col_mul || p.row_div || p.row_mul || p.shift;
     if (let && env_i("OQ_ROWQ_FWD_LET", 1) == 0) return 1;
     const size_t smem = sizeof(float) * ((let ? 2 * p.cols : 0) + 64);
     if (smem > LDS_BUDGET) return 1;
@@ -560,6 +970,33 @@ int oq_rowq_bwd(const FQ& pin, int w_dtype, int g_dtype, float* workspace, int64
     if (pin.seg != pin.cols || env_i("OQ_ROWQ", 1) == 0) return 1;
     FQ p = pin;
     const bool let = p.col_mul || p.row_div || p.row_mul || p.g_col_mul || p.g_shift || p.g_row_div || p.g_row_mul;
+    *partial_rows = 0;
+    if (let && !p.gx) {
+        const int ch = letq_ch(p.cols);
+        if (ch) {
+            const int64_t ngroups = (p.rows + RG - 1) / RG;
+            const int64_t cap = env_i("OQ_LETQ_BWD_BLOCKS", 512);
+            const int64_t nblk = ngroups < cap ? ngroups : cap;
+            if (p.g_col_mul || p.g_shift) {
+                OQ_CHECK_ARG(workspace && workspace_floats >= 2 * nblk * p.cols,
+                             "oq_fakequant_bwd: workspace of %lld floats needed (oq_fakequant_bwd_workspace)", (long long)(2 * nblk * p.cols));
+                p.ws = workspace;
+                *partial_rows = nblk;
+            }
+            const dim3 grid((unsigned)nblk);
+            hipStream_t st = (hipStream_t)stream;
+            switch (w_dtype * 3 + g_dtype) {
+                case OQ_F32 * 3 + OQ_F32: LQ_BWD(float, float); break;
+                case OQ_F32 * 3 + OQ_BF16: LQ_BWD(float, bf16_t); break;
+                case OQ_F16 * 3 + OQ_F32: LQ_BWD(f16_t, float); break;
+                case OQ_F16 * 3 + OQ_BF16: LQ_BWD(f16_t, bf16_t); break;
+                case OQ_BF16 * 3 + OQ_BF16: LQ_BWD(bf16_t, bf16_t); break;
+                default: *partial_rows = 0; return 1;
+            }
+            OQ_CHECK_LAUNCH("oq_fakequant_bwd(letq)");
+            return OQ_OK;
+        }
+    }
     // LET backward (column gradients): the segment kernel's register accumulators win (46 us vs 61 us with the LDS slabs
     // on a 4096 x 4096 weight, same box); the slab variant stays available for A/B
     if (let && env_i("OQ_ROWQ_BWD_LET", 0) == 0) return 1;
@@ -567,7 +1004,6 @@ int oq_rowq_bwd(const FQ& pin, int w_dtype, int g_dtype, float* workspace, int64
     if (!bwd_geo(p, let, &g)) return 1;
     const size_t smem = bwd_smem(p, g, let);
     const int64_t nblk = bwd_grid(p, g, let);
-    *partial_rows = 0;
     if (p.g_col_mul || p.g_shift) {
         OQ_CHECK_ARG(workspace && workspace_floats >= 2 * nblk * p.cols,
                      "oq_fakequant_bwd: workspace of %lld floats needed (oq_fakequant_bwd_workspace)", (long long)(2 * nblk * p.cols));
