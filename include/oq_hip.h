@@ -123,6 +123,15 @@ int oq_rope(const void* x, void* y, int dtype, int64_t T, int64_t heads, int64_t
 int oq_silu_mul_fwd(const void* gate, const void* up, void* y, int dtype, int64_t n, void* stream);
 int oq_silu_mul_bwd(const void* gate, const void* up, const void* gy, void* ggate, void* gup, int dtype, int64_t n,
                     void* stream);
+/* Fused producer + quantiser for the down_proj input of the LLaMA MLP (models/int_llama_layer.py:44-45 followed by the
+ * act_quantizer call of quantize/int_linear.py:59-60): y = per-token fake_quant(silu(gate) * up), rows x cols, cols =
+ * 512 .. 32768 (multiple of 8).  The product reaches the quantiser in fp32 and never goes through memory.  The backward
+ * takes g = dL/dy and the forward's xmin / xmax and writes dL/dgate, dL/dup (straight-through rounding, clip mask and the
+ * amax / amin tie terms of quantize/quantizer.py:122-147 included).  dtype OQ_BF16 or OQ_F32 (all tensors alike). */
+int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype, int64_t rows, int64_t cols, int nbits, void* y,
+                          float* scale, float* zp, float* xmin, float* xmax, void* stream);
+int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int64_t rows, int64_t cols, int nbits,
+                          const float* xmin, const float* xmax, void* ggate, void* gup, void* stream);
 int oq_relu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream);
 int oq_relu_bwd(const void* x, const void* gy, void* gx, int dtype, int64_t n, void* stream);
 int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols, float alpha, const float* mask,

@@ -30,6 +30,8 @@ SIGNATURES = {
     "oq_rope": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
     "oq_silu_mul_fwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_silu_mul_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
+    "oq_silu_mul_quant_fwd": [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "oq_silu_mul_quant_bwd": [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_relu_fwd": [_vp, _vp, _i32, _i64, _vp],
     "oq_relu_bwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_softmax_fwd": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _i64, _i32, _vp],

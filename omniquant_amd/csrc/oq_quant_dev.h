@@ -23,6 +23,9 @@ struct FQ {
     void* gx;
     float *g_col_mul, *g_shift, *g_row_div, *g_row_mul;
     float* ws;   // bwd workspace: [2][gridDim.x][cols] per-workgroup column partials
+    // fused producers (oq_rowq.hip): x = silu(w) * w2 feeds the quantiser directly; the backward writes d/dw to gx, d/dw2 to gx2
+    const void* w2;
+    void* gx2;
 };
 
 namespace {

@@ -86,7 +86,15 @@ __device__ __forceinline__ void row_exchange(float* red, int& par, int wid, int 
 // ---------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------
-template <typename TIN, typename TOUT, bool LET, int CH>
+// PRO = 1: the row is produced on the fly as silu(w) * w2 (QuantLlamaMLP: act_fn(gate_proj(x)) * up_proj(x),
+// models/int_llama_layer.py:44-45) -- the product never goes through memory and reaches the quantiser in fp32.
+__device__ __forceinline__ float silu_f(float g, float* sg_out) {
+    const float sg = sigmoidf_(g);
+    *sg_out = sg;
+    return g * sg;
+}
+
+template <typename TIN, typename TOUT, bool LET, int CH, int PRO = 0>
 __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -124,9 +132,13 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
         if (r >= p.rows) r = p.rows - 1;              // surplus waves redo the last row: same values stored again
         const TIN* wrow = wbase + r * K;
         Raw8<TIN> raw[CH];
+        Raw8<TIN> raw2[PRO ? CH : 1];
 #pragma unroll
         for (int j = 0; j < CH; ++j)
-            if (j < chn) raw[j].load(wrow + cc[j]);
+            if (j < chn) {
+                raw[j].load(wrow + cc[j]);
+                if constexpr (PRO == 1) raw2[j].load(reinterpret_cast<const TIN*>(p.w2) + r * K + cc[j]);
+            }
         const float upl = lwc ? p.up[r] : 0.f, lowl = lwc ? p.low[r] : 0.f;
         const float rd = (LET && p.row_div) ? p.row_div[r] : 1.f;
         const float rm = (LET && p.row_mul) ? p.row_mul[r] : 1.f;
@@ -138,6 +150,12 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
         for (int j = 0; j < CH; ++j) {
             if (j < chn) {
                 raw[j].unpack(x[j]);
+                if constexpr (PRO == 1) {
+                    float u[8], sg;
+                    raw2[j].unpack(u);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x[j][i] = silu_f(x[j][i], &sg) * u[i];
+                }
                 if constexpr (LET) {
                     float cm[8], sh[8];
                     Vec8<float>::load(cm_s + cc[j], cm);
@@ -222,7 +240,7 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
 // ---------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------
-template <typename TIN, typename TG, bool LET, int CH>
+template <typename TIN, typename TG, bool LET, int CH, int PRO = 0>
 __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -262,6 +280,25 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
     const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
     const TG* gbase = reinterpret_cast<const TG*>(p.g);
     TG* gxbase = reinterpret_cast<TG*>(p.gx);
+    TG* gx2base = reinterpret_cast<TG*>(p.gx2);
+    const TIN* w2base = reinterpret_cast<const TIN*>(p.w2);
+    // PRO = 1: x = silu(w) * w2; dL/dx (gin) becomes dL/dw = gin * w2 * silu'(w) -> gx and dL/dw2 = gin * silu(w) -> gx2
+    auto store_grads = [&](int64_t off, const float (&gin)[8], const float (&wv)[8], const float (&uv)[8]) {
+        if constexpr (PRO == 1) {
+            float og[8], ou[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float sg;
+                const float sl = silu_f(wv[i], &sg);
+                ou[i] = gin[i] * sl;
+                og[i] = gin[i] * uv[i] * (sg * (1.f + wv[i] * (1.f - sg)));
+            }
+            Vec8<TG>::store(gxbase + off, og);
+            Vec8<TG>::store(gx2base + off, ou);
+        } else {
+            Vec8<TG>::store(gxbase + off, gin);
+        }
+    };
     const bool lwc = p.up != nullptr;
     int par = 0;
     for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
@@ -278,10 +315,15 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
         bool regular = true;
         if (livew) {
             Raw8<TIN> rw[CH];
+            Raw8<TIN> ru[PRO ? CH : 1];
             Raw8<TG> rg[CH];
 #pragma unroll
             for (int j = 0; j < CH; ++j)
-                if (j < chn) { rw[j].load(wrow + cc[j]); rg[j].load(grow + cc[j]); }
+                if (j < chn) {
+                    rw[j].load(wrow + cc[j]);
+                    rg[j].load(grow + cc[j]);
+                    if constexpr (PRO == 1) ru[j].load(w2base + r * K + cc[j]);
+                }
             hi = p.xmax[r];
             lo = p.xmin[r];
             rd = (LET && p.row_div) ? p.row_div[r] : 1.f;
@@ -295,9 +337,16 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 if (j < chn) {
-                    float w[8], G[8], gin[8];
+                    float w[8], G[8], gin[8], uu[8], xs[8];
                     rw[j].unpack(w);
                     rg[j].unpack(G);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { xs[i] = w[i]; uu[i] = 0.f; }
+                    if constexpr (PRO == 1) {
+                        ru[j].unpack(uu);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { float sg; xs[i] = silu_f(w[i], &sg) * uu[i]; }
+                    }
                     const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
                     const float lv = valid[j] ? 1.f : 0.f;
                     float cm[8], ccm[8], csh[8];
@@ -305,7 +354,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
                     uint64_t tm = 0;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        float v = w[i], a2 = w[i];
+                        float v = xs[i], a2 = xs[i];
                         if constexpr (LET) {
                             v = v * cm[i];
                             a2 = v;
@@ -336,7 +385,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
                         if (need_sh) slab_add(acc_sh, acc_stride / 2, j * 64 + lane, csh);
                     }
                     if (tm != 0) tieflag |= 1u << j;
-                    if (p.gx) Vec8<TG>::store(gxbase + r * K + cc[j], gin);    // tie chunks are rewritten below
+                    if (p.gx) store_grads(r * K + cc[j], gin, w, uu);          // tie chunks are rewritten below
                 }
             }
         }
@@ -384,14 +433,21 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 if (j < chn && ((tieflag >> j) & 1u)) {
-                    float w[8], G[8], gin[8], ccm[8];
+                    float w[8], G[8], gin[8], ccm[8], uu[8], xs[8];
                     Vec8<TIN>::load(wrow + cc[j], w);
                     Vec8<TG>::load(grow + cc[j], G);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { xs[i] = w[i]; uu[i] = 0.f; }
+                    if constexpr (PRO == 1) {
+                        Vec8<TIN>::load(w2base + r * K + cc[j], uu);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { float sg; xs[i] = silu_f(w[i], &sg) * uu[i]; }
+                    }
                     float cm[8];
                     if constexpr (LET) Vec8<float>::load(cm_s + cc[j], cm);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        float v = w[i];
+                        float v = xs[i];
                         if constexpr (LET) {
                             v = v * cm[i];
                             if (p.row_div) v = div_nr(v, rd, inv_rd);
@@ -409,7 +465,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
                     if constexpr (LET) {
                         if (need_cm) slab_add(acc_cm, acc_stride / 2, j * 64 + lane, ccm);
                     }
-                    if (p.gx) Vec8<TG>::store(gxbase + r * K + cc[j], gin);
+                    if (p.gx) store_grads(r * K + cc[j], gin, w, uu);
                 }
             }
         }
@@ -1027,4 +1083,60 @@ int oq_rowq_bwd(const FQ& pin, int w_dtype, int g_dtype, float* workspace, int64
     }
     OQ_CHECK_LAUNCH("oq_fakequant_bwd(rowq)");
     return OQ_OK;
+}
+
+// ---- fused silu(gate) * up -> per-token fake quant (the down_proj input of QuantLlamaMLP) -----------------------------
+template <typename T>
+static int silu_q_launch(bool fwd, FQ& p, void* stream) {
+    RowGeo g;
+    if (!row_geo(p.cols, (int)env_i(fwd ? "OQ_ROWQ_FWD_NW" : "OQ_ROWQ_BWD_NW", 0), &g)) {
+        oq_set_error("oq_silu_mul_quant: rows of %lld elements are not supported (512 .. 32768, multiple of 8)", (long long)p.cols);
+        return OQ_E_UNSUPPORTED;
+    }
+    const int rpb = g.wpb / g.nw;
+    const int64_t need = (p.rows + rpb - 1) / rpb;
+    const int64_t cap = (int64_t)n_cus() * 8;
+    const dim3 grid((unsigned)(need < cap ? need : cap)), blk((unsigned)(g.wpb * 64));
+    const size_t smem = sizeof(float) * 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (fwd) {
+        if (g.chn <= 4) hipLaunchKernelGGL((rowq_fwd_kernel<T, T, false, 4, 1>), grid, blk, smem, st, p, g.nw, g.chn);
+        else hipLaunchKernelGGL((rowq_fwd_kernel<T, T, false, 8, 1>), grid, blk, smem, st, p, g.nw, g.chn);
+    } else {
+        if (g.chn <= 4) hipLaunchKernelGGL((rowq_bwd_kernel<T, T, false, 4, 1>), grid, blk, smem, st, p, g.nw, g.chn);
+        else hipLaunchKernelGGL((rowq_bwd_kernel<T, T, false, 8, 1>), grid, blk, smem, st, p, g.nw, g.chn);
+    }
+    OQ_CHECK_LAUNCH("oq_silu_mul_quant");
+    return OQ_OK;
+}
+
+extern "C" int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype, int64_t rows, int64_t cols, int nbits,
+                                     void* y, float* scale, float* zp, float* xmin, float* xmax, void* stream) {
+    OQ_CHECK_ARG(gate && up && y && scale && zp && xmin && xmax, "oq_silu_mul_quant_fwd: null pointer");
+    OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_silu_mul_quant_fwd: rows %lld, bitwidth %d", (long long)rows, nbits);
+    OQ_CHECK_ARG(oq_aligned16(gate) && oq_aligned16(up) && oq_aligned16(y), "oq_silu_mul_quant_fwd: 16-byte alignment");
+    FQ p{};
+    p.w = gate; p.w2 = up; p.rows = rows; p.cols = cols; p.seg = cols; p.nbits = nbits;
+    p.inv_q = 1.0f / (float)((1 << nbits) - 1);
+    p.y = y; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax;
+    if (dtype == OQ_BF16) return silu_q_launch<bf16_t>(true, p, stream);
+    if (dtype == OQ_F32) return silu_q_launch<float>(true, p, stream);
+    oq_set_error("oq_silu_mul_quant_fwd: dtype %d unsupported", dtype);
+    return OQ_E_UNSUPPORTED;
+}
+
+extern "C" int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int64_t rows, int64_t cols,
+                                     int nbits, const float* xmin, const float* xmax, void* ggate, void* gup, void* stream) {
+    OQ_CHECK_ARG(gate && up && g && ggate && gup && xmin && xmax, "oq_silu_mul_quant_bwd: null pointer");
+    OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_silu_mul_quant_bwd: rows %lld, bitwidth %d", (long long)rows, nbits);
+    OQ_CHECK_ARG(oq_aligned16(gate) && oq_aligned16(up) && oq_aligned16(g) && oq_aligned16(ggate) && oq_aligned16(gup),
+                 "oq_silu_mul_quant_bwd: 16-byte alignment");
+    FQ p{};
+    p.w = gate; p.w2 = up; p.g = g; p.rows = rows; p.cols = cols; p.seg = cols; p.nbits = nbits;
+    p.inv_q = 1.0f / (float)((1 << nbits) - 1);
+    p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax); p.gx = ggate; p.gx2 = gup;
+    if (dtype == OQ_BF16) return silu_q_launch<bf16_t>(false, p, stream);
+    if (dtype == OQ_F32) return silu_q_launch<float>(false, p, stream);
+    oq_set_error("oq_silu_mul_quant_bwd: dtype %d unsupported", dtype);
+    return OQ_E_UNSUPPORTED;
 }

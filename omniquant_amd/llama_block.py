@@ -36,6 +36,16 @@ class QuantLlamaMLP(nn.Module):
     def forward(self, x, residual=None):
         xq = self.gate_proj.quantize_input(x)       # gate/up share one act-quant pass (identical settings)
         gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq)
+        dq = self.down_proj.act_quantizer
+        if (self.down_proj.use_act_quant and dq is not None and not self.down_proj.disable_input_quant and dq.enable
+                and dq.n_bits < 16 and not dq.symmetric and dq.metric != "fix0to1" and not dq.group_size
+                and dq.dynamic_method == "per_token" and not dq.lwc and self.down_proj.__dict__.get("_stat_sink") is None
+                and ops.silu_mul_quant_supported(gate, dq.n_bits)):
+            # act_fn(gate) * up and the down_proj input quantiser in ONE kernel: the product is never stored
+            stash = {}
+            act = ops.SiluMulQuantFn.apply(gate, up, dq.n_bits, stash)
+            dq.scale, dq.round_zero_point = stash["scale"], stash["zp"]
+            return self.down_proj(act, input_is_quantized=True, residual=residual)
         return self.down_proj(ops.SiluMulFn.apply(gate, up), residual=residual)   # residual add fused into the GEMM store
 
 

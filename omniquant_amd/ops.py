@@ -464,6 +464,49 @@ class SiluMulFn(torch.autograd.Function):
         return gg, gu
 
 
+def silu_mul_quant_supported(gate, nbits):
+    """The fused silu*up -> per-token fake-quant kernels take bf16 / f32 rows of 512 .. 32768 elements (multiple of 8).
+    OQ_NO_FUSED_SILUQ=1 is an A/B switch."""
+    if os.environ.get("OQ_NO_FUSED_SILUQ"):
+        return False
+    k = gate.shape[-1]
+    return gate.is_cuda and gate.dtype in (torch.bfloat16, torch.float32) and 2 <= nbits < 16 and k % 8 == 0 and 512 <= k <= 32768
+
+
+class SiluMulQuantFn(torch.autograd.Function):
+    """y = per_token_fake_quant(silu(gate) * up): QuantLlamaMLP's act_fn(gate) * up (models/int_llama_layer.py:44-45)
+    fused with the down_proj input quantiser (quantize/int_linear.py:59-60, quantize/quantizer.py:84-147).  One kernel per
+    direction; the product stays in fp32 registers between the two reference steps."""
+
+    @staticmethod
+    def forward(ctx, gate, up, nbits, stash):
+        gate, up = gate.contiguous(), up.contiguous()
+        cols = gate.shape[-1]
+        rows = gate.numel() // cols
+        y = torch.empty_like(gate)
+        scale, zp, xmin, xmax = (torch.empty((rows, 1), dtype=torch.float32, device=gate.device) for _ in range(4))
+        C.call("oq_silu_mul_quant_fwd", C.ptr(gate), C.ptr(up), C.dt(gate), rows, cols, int(nbits), C.ptr(y),
+               C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
+        if stash is not None:
+            stash["scale"], stash["zp"] = scale, zp
+        ctx.save_for_backward(gate, up, xmin, xmax)
+        ctx.nbits = int(nbits)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gate, up, xmin, xmax = ctx.saved_tensors
+        gy = gy.contiguous()
+        if gy.dtype != gate.dtype:
+            gy = gy.to(gate.dtype)
+        cols = gate.shape[-1]
+        rows = gate.numel() // cols
+        gg, gu = torch.empty_like(gate), torch.empty_like(up)
+        C.call("oq_silu_mul_quant_bwd", C.ptr(gate), C.ptr(up), C.ptr(gy), C.dt(gate), rows, cols, ctx.nbits,
+               C.fptr(xmin), C.fptr(xmax), C.ptr(gg), C.ptr(gu), C.stream())
+        return gg, gu, None, None
+
+
 class ReluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -477,7 +477,11 @@ class Block:
             h2 = R_(self._norm(h, nm["ln2"], temps))
             gate = self._lin(h2, "mlp.gate_proj", temps, act_quant, rnd)
             up = self._lin(h2, "mlp.up_proj", temps, act_quant, rnd)
-            return self._lin(R_(F.silu(gate) * up), "mlp.down_proj", temps, act_quant, rnd, residual=h)
+            act = F.silu(gate) * up
+            if not aq4:
+                act = R_(act)          # stored before the GEMM; with activation quantisation on, the product path fuses
+                #                        silu*up into the down_proj input quantiser and the product stays fp32
+            return self._lin(act, "mlp.down_proj", temps, act_quant, rnd, residual=h)
         # ---- OPT: q/k/v are quantised per token over the full hidden dim before the head split
         scaling = self.hd ** -0.5
         q = self._aq(R_(self._lin(h, nm["q"], temps, act_quant, rnd) * scaling), act_quant)

@@ -599,3 +599,34 @@ def test_identity_grid_keeps_the_let_transform():
     assert w16.dtype == torch.bfloat16 and torch.equal(w16, W.to(DEV).to(torch.bfloat16))
     q.register_scales_and_zeros()                                     # tolerates scale = None like the reference
     assert q.scales is None and q.zeros is None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(64, 11008), (33, 4096), (16, 13824), (5, 28672), (7, 520)])
+def test_silu_mul_quant_fused_vs_oracle(dtype, rows, cols):
+    """y = per_token_fake_quant(silu(gate) * up) in one kernel per direction (models/int_llama_layer.py:44-45 +
+    quantize/int_linear.py:59-60) vs the CPU oracle's two steps: output, both input gradients (clip mask, straight-through
+    rounding and amax / amin tie terms included) and the stashed scale / zero-point."""
+    from oracle import ref_cpu as R
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    gate = (torch.randn(rows, cols, generator=g) * 1.5).to(dtype)
+    up = torch.randn(rows, cols, generator=g).to(dtype)
+    G = torch.randn(rows, cols, generator=g).to(dtype)
+    go, uo = gate.float().clone().requires_grad_(True), up.float().clone().requires_grad_(True)
+    yo, so, zo = R.fake_quant(torch.nn.functional.silu(go) * uo, 4, return_qparams=True)
+    (yo * G.float()).sum().backward()
+    gd, ud = gate.to(DEV).requires_grad_(True), up.to(DEV).requires_grad_(True)
+    assert ops.silu_mul_quant_supported(gd, 4)
+    stash = {}
+    yd = ops.SiluMulQuantFn.apply(gd, ud, 4, stash)
+    assert yd.dtype == dtype
+    f32 = dtype == torch.float32
+    step = float(so.max())
+    assert_close(stash["scale"], so.detach().numpy(), 5e-6, 1e-9, "scale")
+    assert_close(yd.float(), yo.detach().numpy(), 1e-5 if f32 else 8e-3, 1e-6 if f32 else 1e-2 * step, "y", max_bad_frac=0.003)
+    assert_close(yd.float(), yo.detach().numpy(), 0, 1.02 * step, "y (one step)")
+    (yd.float() * G.to(DEV).float()).sum().backward()
+    for name, a, b in (("dgate", gd.grad, go.grad), ("dup", ud.grad, uo.grad)):
+        sc = float(b.abs().max())
+        assert_close(a.float() / sc, b.numpy() / sc, 2e-3 if f32 else 1e-2, 2e-4 if f32 else 4e-3, name, max_bad_frac=0.003)
