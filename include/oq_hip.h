@@ -123,6 +123,16 @@ int oq_rope(const void* x, void* y, int dtype, int64_t T, int64_t heads, int64_t
 int oq_silu_mul_fwd(const void* gate, const void* up, void* y, int dtype, int64_t n, void* stream);
 int oq_silu_mul_bwd(const void* gate, const void* up, const void* gy, void* ggate, void* gup, int dtype, int64_t n,
                     void* stream);
+/* RoPE + head-wise fake quant of a projection output in one kernel per direction (head_dim 128): x [rows = bs*T, nh, 128]
+ * (OQ_BF16 or OQ_F32) -> y = fake_quant_per_(token, head)(x * cos + rotate_half(x) * sin), cos / sin [T, 128] f32 already
+ * gathered by position (both NULL: no rotation, the v path).  Replaces apply_rotary_pos_emb + qkt_matmul.quant_x1/x2 /
+ * pv_matmul.quant_x2 (models/int_llama_layer.py:124-125,140-143,161 -> quantize/quantizer.py:84-147).  scale, zp, xmin,
+ * xmax: [rows*nh] f32; the backward needs xmin / xmax and writes gx = dL/dx (g_dtype) from g = dL/dy. */
+int64_t oq_rope_quant_supported(int dtype, int hd);
+int oq_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nh, int hd, const float* cos, const float* sin,
+                      int nbits, void* y, int y_dtype, float* scale, float* zp, float* xmin, float* xmax, void* stream);
+int oq_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nh, int hd, const float* cos, const float* sin,
+                      int nbits, const float* xmin, const float* xmax, const void* g, int g_dtype, void* gx, void* stream);
 /* Fused producer + quantiser for the down_proj input of the LLaMA MLP (models/int_llama_layer.py:44-45 followed by the
  * act_quantizer call of quantize/int_linear.py:59-60): y = per-token fake_quant(silu(gate) * up), rows x cols, cols =
  * 512 .. 32768 (multiple of 8).  The product reaches the quantiser in fp32 and never goes through memory.  The backward

@@ -100,6 +100,21 @@ class QuantLlamaAttention(nn.Module):
         self._rope_cache = ((T, str(device)), position_ids, None if position_ids is None else position_ids._version, cos, sin)
         return cos, sin
 
+    def _fused_rope_quant(self, hq):
+        """True when q / k / v can take the fused projection -> RoPE -> head-wise quant node: the three head quantisers are
+        the plain dynamic per-token asymmetric ones (what main.py builds), head_dim 128, HIP GEMM projections."""
+        from .linear import _hip_linear
+        if not (self.qkt_matmul.use_act_quant and self.pv_matmul.use_act_quant):
+            return False
+        for qz in (self.qkt_matmul.x1_quantizer, self.qkt_matmul.x2_quantizer, self.pv_matmul.x2_quantizer):
+            if not (qz.enable and 2 <= qz.n_bits < 16 and not qz.symmetric and not qz.lwc and not qz.group_size
+                    and qz.metric != "fix0to1" and qz.dynamic_method == "per_token"):
+                return False
+        for lin in (self.q_proj, self.k_proj, self.v_proj):
+            if lin.fwd_func is not _hip_linear or lin.fwd_kwargs or lin.__dict__.get("_stat_sink") is not None:
+                return False
+        return ops.rope_quant_supported(hq.dtype, self.head_dim)
+
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
                 output_attentions=False, use_cache=False, residual=None):
         if past_key_value is not None or use_cache or output_attentions:
@@ -107,14 +122,28 @@ class QuantLlamaAttention(nn.Module):
         bsz, q_len, _ = hidden_states.size()
         nh, nkv, hd = self.num_heads, self.num_key_value_heads, self.head_dim
         hq = self.q_proj.quantize_input(hidden_states)      # q/k/v share one act-quant pass
-        q, k, v = QuantLinear.forward_siblings([self.q_proj, self.k_proj, self.v_proj], hq)
-        q, k, v = q.view(bsz, q_len, nh, hd), k.view(bsz, q_len, nkv, hd), v.view(bsz, q_len, nkv, hd)
         cos, sin = self._rope_tables(position_ids, q_len, hidden_states.device)
-        q = ops.RopeFn.apply(q, cos, sin)
-        k = ops.RopeFn.apply(k, cos, sin)
-        # head-wise (per head, per token) fake quant over head_dim; repeat_kv commutes with it
-        q = self.qkt_matmul.quant_x1(q)
-        k = self.qkt_matmul.quant_x2(k)
+        fused_qkv = self._fused_rope_quant(hq)
+        if fused_qkv:
+            # projection -> RoPE -> head-wise fake quant as one node per tensor: the projection output stays fp32 inside it
+            outs = []
+            for lin, qz, rot in ((self.q_proj, self.qkt_matmul.x1_quantizer, True), (self.k_proj, self.qkt_matmul.x2_quantizer, True),
+                                 (self.v_proj, self.pv_matmul.x2_quantizer, False)):
+                w, b = lin._resolve(hq.dtype)
+                if w.dtype != hq.dtype:
+                    w = ops.cast(w, hq.dtype)
+                stash = {}
+                outs.append(ops.LinearRopeQuantFn.apply(hq, w, b, cos if rot else None, sin if rot else None, qz.n_bits, hd, stash))
+                qz.scale, qz.round_zero_point = stash["scale"], stash["zp"]
+            q, k, v = outs
+        else:
+            q, k, v = QuantLinear.forward_siblings([self.q_proj, self.k_proj, self.v_proj], hq)
+            q, k, v = q.view(bsz, q_len, nh, hd), k.view(bsz, q_len, nkv, hd), v.view(bsz, q_len, nkv, hd)
+            q = ops.RopeFn.apply(q, cos, sin)
+            k = ops.RopeFn.apply(k, cos, sin)
+            # head-wise (per head, per token) fake quant over head_dim; repeat_kv commutes with it
+            q = self.qkt_matmul.quant_x1(q)
+            k = self.qkt_matmul.quant_x2(k)
         mask = None
         if attention_mask is not None:
             if attention_mask.size() != (bsz, 1, q_len, q_len):
@@ -127,13 +156,15 @@ class QuantLlamaAttention(nn.Module):
         if p_identity and ops.fused_attention_supported(q, causal):
             # exact causal mask + identity p-quantiser (the reference default, 16 bit): one fused kernel per direction,
             # the [nh, T, T] scores / probabilities never touch HBM
-            v = self.pv_matmul.quant_x2(v)
+            if not fused_qkv:
+                v = self.pv_matmul.quant_x2(v)
             attn = ops.FusedCausalAttnFn.apply(q, k, v, 1.0 / math.sqrt(hd))
         else:
             scores = self.qkt_matmul.scores(q, k, causal)               # [bs, nh, T, T], unscaled
             probs = ops.SoftmaxFn.apply(scores, mask, 1.0 / math.sqrt(hd), causal)   # scale, +mask, clamp, f32 softmax
             probs = self.pv_matmul.quant_x1(probs)
-            v = self.pv_matmul.quant_x2(v)
+            if not fused_qkv:
+                v = self.pv_matmul.quant_x2(v)
             attn = self.pv_matmul.apply_probs(probs, v, causal)        # [bs, T, nh, hd]
         attn = self.o_proj(attn.view(bsz, q_len, self.hidden_size), residual=residual)   # (+ residual in the GEMM store)
         return attn, None, None

@@ -210,6 +210,73 @@ class LinearFn(torch.autograd.Function):
         return gx, gw, gb, gres
 
 
+def rope_quant_supported(dtype, hd):
+    """Fused projection -> RoPE -> head-wise fake quant (bf16 / f32, head_dim 128).  OQ_NO_FUSED_ROPEQ=1: A/B switch."""
+    if os.environ.get("OQ_NO_FUSED_ROPEQ") or dtype not in C._DT:
+        return False
+    return bool(C.size_call("oq_rope_quant_supported", C._DT[dtype], int(hd)))
+
+
+class LinearRopeQuantFn(torch.autograd.Function):
+    """y = fake_quant_head(rope(x @ wq.T + bias)) for one of q / k (cos, sin given) or fake_quant_head(x @ wq.T + bias)
+    for v (cos = sin = None): quantize/int_linear.py:62 -> models/int_llama_layer.py:124-125 -> quant_x1 / quant_x2
+    (:140-143,161) as ONE autograd node: the rotated tensor is never stored (two 16.8 MB round trips per direction at
+    LLaMA-7B) and is not rounded to bf16 in front of the 4-bit rounding decision.  The projection's output lives only
+    inside this node; OQ_QKV_F32=1 keeps it in fp32 as well (measured: 1 % slower, and the gradients of the q / k path
+    agree no better with an fp32 run -- their rounding flips come from the shared 4-bit INPUT of the projections).
+    x [bs, T, K]; returns y [bs, T, nh, hd]."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bias, cos, sin, nbits, hd, stash):
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        wq = wq.contiguous()
+        rows, K = x2.shape
+        N = wq.shape[0]
+        nh = N // hd
+        if wq.dtype != x2.dtype:
+            raise C.OQError(f"LinearRopeQuantFn: weight dtype {wq.dtype} != activation dtype {x2.dtype}")
+        pre_dtype = torch.float32 if os.environ.get("OQ_QKV_F32") else x2.dtype
+        pre = torch.empty((rows, N), dtype=pre_dtype, device=x2.device)
+        gemm(x2, wq, pre, rows, N, K, K, K, N, True, True, bias=_f32(bias))
+        y = torch.empty((rows, N), dtype=x2.dtype, device=x2.device)
+        scale, zp, xmin, xmax = (torch.empty((rows * nh, 1), dtype=torch.float32, device=x2.device) for _ in range(4))
+        T = x.shape[-2]
+        C.call("oq_rope_quant_fwd", C.ptr(pre), C.dt(pre), rows, T, nh, hd, C.fptr(cos), C.fptr(sin), int(nbits),
+               C.ptr(y), C.dt(y), C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
+        if stash is not None:
+            stash["scale"], stash["zp"] = scale, zp
+        ctx.save_for_backward(x2, wq, pre, xmin, xmax, cos, sin)
+        ctx.cfg = (T, nh, hd, int(nbits), bias is not None, x.shape)
+        return y.view(*x.shape[:-1], nh, hd)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, wq, pre, xmin, xmax, cos, sin = ctx.saved_tensors
+        T, nh, hd, nbits, has_bias, xshape = ctx.cfg
+        rows, K = x2.shape
+        N = wq.shape[0]
+        gy = gy.contiguous()
+        if gy.dtype != x2.dtype:
+            gy = gy.to(x2.dtype)
+        gpre = torch.empty((rows, N), dtype=x2.dtype, device=x2.device)
+        C.call("oq_rope_quant_bwd", C.ptr(pre), C.dt(pre), rows, T, nh, hd, C.fptr(cos), C.fptr(sin), nbits,
+               C.fptr(xmin), C.fptr(xmax), C.ptr(gy), C.dt(gy), C.ptr(gpre), C.stream())
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty((rows, K), dtype=x2.dtype, device=x2.device)
+            gemm(gpre, wq, gx, rows, K, N, N, K, K, True, False)
+            gx = gx.view(xshape)
+        if ctx.needs_input_grad[1]:
+            gw = torch.empty((N, K), dtype=wq.dtype, device=x2.device)
+            gemm(gpre, x2, gw, N, K, rows, N, K, K, False, False)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty((N,), dtype=torch.float32, device=x2.device)
+            ws_n = C.size_call("oq_colsum_workspace", rows, N)
+            ws = torch.empty(ws_n, dtype=torch.float32, device=x2.device)
+            C.call("oq_colsum", C.ptr(gpre), C.dt(gpre), rows, N, C.fptr(gb), C.fptr(ws), ws_n, C.stream())
+        return gx, gw, gb, None, None, None, None, None
+
+
 class SiblingLinearFn(torch.autograd.Function):
     """Projections that read the SAME input (q/k/v; gate/up): y_i = x @ w_i.T + b_i.  One autograd node, so the
     input gradient dX = sum_i dY_i @ W_i is ACCUMULATED by the dgrad GEMMs' epilogue (addend = the running sum) instead

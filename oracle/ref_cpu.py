@@ -421,7 +421,7 @@ class Block:
             return (w * xh + b).to(x.dtype) if b is not None else (w * xh).to(x.dtype)
         return F.layer_norm(x, (self.H,), w, b, eps=self.eps)
 
-    def _lin(self, x, name, t, act_quant, rnd=None, residual=None):
+    def _lin(self, x, name, t, act_quant, rnd=None, residual=None, round_out=True):
         w = t[name + ".weight"] if t else self.w[name + ".weight"]
         b = t[name + ".bias"] if t else self.w.get(name + ".bias")
         xin = self._aq(x, act_quant)
@@ -430,7 +430,7 @@ class Block:
         y = F.linear(xin, w, b)
         if residual is not None:
             y = residual + y                                # (the product path adds the residual in the GEMM's store)
-        return rnd(y) if rnd is not None else y
+        return rnd(y) if (rnd is not None and round_out) else y
 
     def forward(self, x, mask=None, position_ids=None, temps=None, act_quant=True, act_dtype=None):
         """x [bs,T,H].  temps=None -> raw (or folded) weights; act_quant toggles every activation quantizer.
@@ -444,13 +444,18 @@ class Block:
         aq4 = act_quant and self.spec.abits < 16
         h = R_(self._norm(x, nm["ln1"], temps))
         if self.family == "llama":
+            # with head-wise activation quantisation on (head_dim 128), the product path rotates and quantises the stored
+            # projection output in one kernel: the rotated tensor is never stored
+            keep = act_dtype is not None and aq4 and self.hd == 128
             q = self._lin(h, nm["q"], temps, act_quant, rnd).view(bs, T, self.nh, self.hd).transpose(1, 2)
             k = self._lin(h, nm["k"], temps, act_quant, rnd).view(bs, T, self.nkv, self.hd).transpose(1, 2)
             v = self._lin(h, nm["v"], temps, act_quant, rnd).view(bs, T, self.nkv, self.hd).transpose(1, 2)
             cos = self.cos[:T][position_ids].unsqueeze(1)
             sin = self.sin[:T][position_ids].unsqueeze(1)
-            q = R_(q * cos + _rot_half(q) * sin)
-            k = R_(k * cos + _rot_half(k) * sin)
+            q = q * cos + _rot_half(q) * sin
+            k = k * cos + _rot_half(k) * sin
+            if not keep:
+                q, k = R_(q), R_(k)
             rep = self.nh // self.nkv
             if rep > 1:
                 k = k[:, :, None].expand(bs, self.nkv, rep, T, self.hd).reshape(bs, self.nh, T, self.hd)

@@ -630,3 +630,45 @@ def test_silu_mul_quant_fused_vs_oracle(dtype, rows, cols):
     for name, a, b in (("dgate", gd.grad, go.grad), ("dup", ud.grad, uo.grad)):
         sc = float(b.abs().max())
         assert_close(a.float() / sc, b.numpy() / sc, 2e-3 if f32 else 1e-2, 2e-4 if f32 else 4e-3, name, max_bad_frac=0.003)
+
+
+@pytest.mark.parametrize("in_dtype,out_dtype", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("rot", [True, False])
+def test_rope_quant_fused_vs_oracle(in_dtype, out_dtype, rot):
+    """RoPE + per-(token, head) fake quant in one kernel per direction (models/int_llama_layer.py:124-125,140-143,161)
+    vs the CPU oracle's two steps (transformers-4.31 rotate_half formula + quantize/quantizer.py:84-147), forward and the
+    gradient w.r.t. the un-rotated input; rot=False is the v path (quantiser only)."""
+    from oracle import ref_cpu as R
+    from omniquant_amd import _capi as C
+    g = torch.Generator().manual_seed(5 + int(rot))
+    bs, Tn, nh, hd = 2, 24, 3, 128
+    x = torch.randn(bs, Tn, nh, hd, generator=g).to(in_dtype)
+    G = torch.randn(bs, Tn, nh, hd, generator=g).to(out_dtype)
+    cos, sin = R._rope_tables(hd, Tn)
+    xo = x.float().clone().requires_grad_(True)
+    xr = xo
+    if rot:
+        c, s = cos[None, :, None, :], sin[None, :, None, :]
+        xr = xo * c + R._rot_half(xo) * s
+    yo, so, zo = R.fake_quant(xr, 4, return_qparams=True)
+    (yo * G.float()).sum().backward()
+    xd = x.to(DEV).contiguous()
+    rows = bs * Tn
+    y = torch.empty(rows, nh * hd, device=DEV, dtype=out_dtype)
+    sc, zp, mn, mx = (torch.empty(rows * nh, device=DEV) for _ in range(4))
+    cd, sd = (cos.to(DEV).contiguous(), sin.to(DEV).contiguous()) if rot else (None, None)
+    assert C.size_call("oq_rope_quant_supported", C._DT[in_dtype], hd) == 1
+    C.call("oq_rope_quant_fwd", C.ptr(xd), C.dt(xd), rows, Tn, nh, hd, C.fptr(cd), C.fptr(sd), 4, C.ptr(y), C.dt(y),
+           C.fptr(sc), C.fptr(zp), C.fptr(mn), C.fptr(mx), C.stream())
+    f32 = out_dtype == torch.float32 and in_dtype == torch.float32
+    step = float(so.detach().max())
+    assert_close(sc, so.detach().numpy().reshape(-1), 5e-6, 1e-9, "scale")
+    assert_close(y.float().view(bs, Tn, nh, hd), yo.detach().numpy(), 1e-5 if f32 else 8e-3, 1e-6 if f32 else 1e-2 * step, "y",
+                 max_bad_frac=0.003)
+    Gd = G.to(DEV).contiguous()
+    gx = torch.empty(rows, nh * hd, device=DEV, dtype=out_dtype)
+    C.call("oq_rope_quant_bwd", C.ptr(xd), C.dt(xd), rows, Tn, nh, hd, C.fptr(cd), C.fptr(sd), 4, C.fptr(mn), C.fptr(mx),
+           C.ptr(Gd), C.dt(Gd), C.ptr(gx), C.stream())
+    scg = float(xo.grad.abs().max())
+    assert_close(gx.float().view(bs, Tn, nh, hd) / scg, xo.grad.numpy() / scg, 2e-3 if f32 else 1e-2, 2e-4 if f32 else 6e-3, "gx",
+                 max_bad_frac=0.003)
