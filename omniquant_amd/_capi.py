@@ -30,6 +30,8 @@ SIGNATURES = {
     "oq_rope": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
     "oq_silu_mul_fwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_silu_mul_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
+    "oq_norm_quant_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "oq_norm_quant_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_rope_quant_fwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_rope_quant_bwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "oq_silu_mul_quant_fwd": [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -57,7 +59,8 @@ SIGNATURES = {
 # functions returning a size instead of an error code
 SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64],
               "oq_attn_supported": [_i32, _i64, _i32, _i32], "oq_act_stats_workspace": [_i64, _i64],
-              "oq_colsum_workspace": [_i64, _i64], "oq_rope_quant_supported": [_i32, _i32]}
+              "oq_colsum_workspace": [_i64, _i64], "oq_rope_quant_supported": [_i32, _i32],
+              "oq_norm_quant_supported": [_i32, _i64], "oq_norm_quant_bwd_workspace": [_i64, _i64]}
 
 _lib = None
 

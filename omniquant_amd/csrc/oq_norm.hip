@@ -3,6 +3,7 @@
 // Backward column sums (gw, gb) are accumulated in registers over the rows a workgroup walks, written as one partial
 // row per workgroup and finished by norm_colreduce_kernel in a fixed order (no atomics).
 #include "oq_common.h"
+#include "oq_quant_dev.h"
 
 namespace {
 constexpr int MAXCH = 4;
@@ -191,6 +192,325 @@ __global__ void __launch_bounds__(256) norm_colreduce_kernel(const float* part, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// norm -> per-token fake quant in one kernel per direction
+// ---------------------------------------------------------------------------------------------------
+// y = fake_quant_per_token(norm(x)): OmniLlamaRMSNorm / OmniLayerNorm (quantize/omni_norm.py:26-34,52-63) followed by
+// the act_quantizer of the first QuantLinear behind it (quantize/int_linear.py:59-60 -> quantize/quantizer.py:84-147).
+// The normalised row never goes through memory and reaches the quantiser in fp32 (unfused it was stored in bf16 right
+// in front of the 4-bit rounding decision).  Geometry of oq_rowq.hip: nw waves per row (2 for hidden sizes up to 4096),
+// up to 8 chunks of 8 per lane, one LDS exchange per row-wide reduction; the norm weight / bias live in LDS.
+// Backward: recomputes h = norm(x), applies the quantiser's closed-form gradient (clip mask, straight-through rounding,
+// amax / amin tie terms) to get dL/dh, then the norm backward; gw / gb column sums accumulate in registers (lane ->
+// column ownership is fixed) and leave as one partial row per workgroup (norm_colreduce_kernel finishes).
+struct NQ {
+    const void* x;
+    void* y;
+    const float *w, *b;
+    int64_t rows, cols;
+    float eps;
+    int ln, nbits;
+    float inv_q;
+    float *rstd, *mean, *scale, *zp, *xmin, *xmax;
+    const void* g;
+    void* gx;
+    const void* gx_add;
+    float* ws;
+    int want_b;
+};
+
+template <typename TIN, typename TOUT, int CH>
+__global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int rpb = wpb / nw;
+    const int rslot = wid / nw, wsub = wid - rslot * nw;
+    const int K = (int)p.cols;
+    const int nchunks = K >> 3;
+    float* w_s = smem;
+    float* b_s = smem + K;
+    float* red = smem + 2 * K;
+    const float Q = (float)((1 << p.nbits) - 1);
+    for (int i = threadIdx.x * 4; i < K; i += blockDim.x * 4) {
+        *reinterpret_cast<f32x4*>(w_s + i) = *reinterpret_cast<const f32x4*>(p.w + i);
+        *reinterpret_cast<f32x4*>(b_s + i) = p.b ? *reinterpret_cast<const f32x4*>(p.b + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    bool valid[CH];
+    int cc[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = (j * nw + wsub) * 64 + lane;
+        valid[j] = c < nchunks;
+        cc[j] = (valid[j] ? c : nchunks - 1) * 8;
+    }
+    const TIN* xbase = reinterpret_cast<const TIN*>(p.x);
+    TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
+    const float invK = 1.f / (float)K;
+    int par = 0;
+    for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
+        int64_t r = r0 + rslot;
+        if (r >= p.rows) r = p.rows - 1;
+        float v[CH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (j < chn) {
+                Vec8<TIN>::load(xbase + r * K + cc[j], v[j]);
+                const float lv = valid[j] ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) s += lv * (p.ln ? v[j][i] : v[j][i] * v[j][i]);
+            }
+        const int op0[4] = {0, 0, 0, 0};
+        float e4[4] = {wave_sum(s), 0.f, 0.f, 0.f};
+        if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, e4, op0);
+        float mean = 0.f, var;
+        if (p.ln) {
+            mean = e4[0] * invK;
+            float s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (j < chn && valid[j]) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const float d = v[j][i] - mean; s2 += d * d; }
+                }
+            float f4[4] = {wave_sum(s2), 0.f, 0.f, 0.f};
+            if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, f4, op0);
+            var = f4[0] * invK;
+        } else {
+            var = e4[0] * invK;
+        }
+        const float rstd = rsqrtf(var + p.eps);
+        float hi = -INFINITY, lo = INFINITY;
+        uint64_t nanm = 0;
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (j < chn) {
+                float wv[8], bv[8];
+                Vec8<float>::load(w_s + cc[j], wv);
+                Vec8<float>::load(b_s + cc[j], bv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xh = (v[j][i] - mean) * rstd;
+                    const float h = wv[i] * xh + bv[i];
+                    v[j][i] = h;
+                    hi = vmax(hi, h);
+                    lo = vmin(lo, h);
+                    nanm |= __builtin_amdgcn_fcmpf(h, h, 8);
+                }
+            }
+        float m4[4] = {wave_max(hi), wave_min(lo), nanm != 0 ? 1.f : 0.f, 0.f};
+        if (nw > 1) {
+            const int op[4] = {1, 2, 1, 0};
+            row_exchange(red, par, wid, rslot, nw, lane, m4, op);
+        }
+        hi = m4[0]; lo = m4[1];
+        const float bad = m4[2];
+        if (bad != 0.f) { hi = NAN; lo = NAN; }
+        float inv_s = 0.f;
+        const QP q = make_qp(hi, lo, false, 0.f, 0.f, p.nbits, 0, p.inv_q, &inv_s);
+        const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad == 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (j < chn) {
+                float yv[8];
+                if (regular) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float tq;
+                        const float rq = rne_div(v[j][i], q.s, inv_s, &tq);
+                        yv[i] = (__builtin_amdgcn_fmed3f(rq + q.z, 0.f, Q) - q.z) * q.s;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float t = rne_ste(v[j][i] / q.s) + q.z;
+                        t = (t != t) ? t : fminf(fmaxf(t, 0.f), Q);
+                        yv[i] = (t - q.z) * q.s;
+                    }
+                }
+                Vec8<TOUT>::store(ybase + r * K + cc[j], yv);
+            }
+        if (wsub == 0) {
+            p.rstd[r] = rstd;
+            if (p.mean) p.mean[r] = mean;
+            p.scale[r] = q.s;
+            p.zp[r] = q.z;
+            p.xmin[r] = lo;
+            p.xmax[r] = hi;
+        }
+    }
+}
+
+template <typename TIN, typename TG, int CH>
+__global__ void __launch_bounds__(512) normq_bwd_kernel(NQ p, int nw, int chn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wpb = (int)(blockDim.x >> 6);
+    const int rpb = wpb / nw;
+    const int rslot = wid / nw, wsub = wid - rslot * nw;
+    const int K = (int)p.cols;
+    const int nchunks = K >> 3;
+    float* w_s = smem;
+    float* b_s = smem + K;
+    float* red = smem + 2 * K;           // 64 floats
+    float* fold = red + 64;              // [wpb][chn*512] for the final cross-wave sum of the column accumulators
+    const float Q = (float)((1 << p.nbits) - 1);
+    for (int i = threadIdx.x * 4; i < K; i += blockDim.x * 4) {
+        *reinterpret_cast<f32x4*>(w_s + i) = *reinterpret_cast<const f32x4*>(p.w + i);
+        *reinterpret_cast<f32x4*>(b_s + i) = p.b ? *reinterpret_cast<const f32x4*>(p.b + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    bool valid[CH];
+    int cc[CH];
+    float aw[CH][8], ab[CH][8];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+        const int c = (j * nw + wsub) * 64 + lane;
+        valid[j] = c < nchunks;
+        cc[j] = (valid[j] ? c : nchunks - 1) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { aw[j][i] = 0.f; ab[j][i] = 0.f; }
+    }
+    const TIN* xbase = reinterpret_cast<const TIN*>(p.x);
+    const TG* gbase = reinterpret_cast<const TG*>(p.g);
+    const TG* abase = reinterpret_cast<const TG*>(p.gx_add);
+    TG* gxbase = reinterpret_cast<TG*>(p.gx);
+    const float invK = 1.f / (float)K;
+    int par = 0;
+    for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
+        const bool livew = r0 + rslot < p.rows;
+        const int64_t r = livew ? r0 + rslot : p.rows - 1;
+        const float live = livew ? 1.f : 0.f;
+        const float rstd = p.rstd[r];
+        const float mean = (p.ln && p.mean) ? p.mean[r] : 0.f;
+        const float hi = p.xmax[r], lo = p.xmin[r];
+        float inv_s = 0.f;
+        const QP q = make_qp(hi, lo, false, 0.f, 0.f, p.nbits, 0, p.inv_q, &inv_s);
+        const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f;
+        float xh[CH][8], gh[CH][8];
+        float gs = 0.f;
+        int whi = 0, wlo = 0;
+        uint32_t tieflag = 0;
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (j < chn) {
+                float G[8], wv[8], bv[8];
+                Vec8<TIN>::load(xbase + r * K + cc[j], xh[j]);
+                Vec8<TG>::load(gbase + r * K + cc[j], G);
+                Vec8<float>::load(w_s + cc[j], wv);
+                Vec8<float>::load(b_s + cc[j], bv);
+                const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
+                const float lv = valid[j] ? live : 0.f;
+                uint64_t tm = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    xh[j][i] = (xh[j][i] - mean) * rstd;
+                    const float h = wv[i] * xh[j][i] + bv[i];
+                    const float tq = h * inv_s;
+                    const float u = (regular ? rintf(tq) : rne_ste(tq)) + q.z;
+                    const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
+                    const bool in = qv == u;
+                    const float Gr = G[i] * lv;
+                    gs = fmaf(Gr, (qv - q.z) - (in ? tq : 0.f), gs);
+                    const uint64_t mh = __builtin_amdgcn_fcmpf(h, hi, 1) & vmask;
+                    const uint64_t ml = __builtin_amdgcn_fcmpf(h, lo, 1) & vmask;
+                    whi += __builtin_popcountll(mh);
+                    wlo += __builtin_popcountll(ml);
+                    tm |= mh | ml;
+                    gh[j][i] = in ? Gr : 0.f;
+                }
+                if (tm != 0) tieflag |= 1u << j;
+            }
+        const int op0[4] = {0, 0, 0, 0};
+        float e4[4] = {wave_sum(gs), (float)whi, (float)wlo, 0.f};
+        if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, e4, op0);
+        if (tieflag != 0) {
+            const float tie_hi = (e4[0] / Q) / e4[1], tie_lo = -(e4[0] / Q) / e4[2];
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (j < chn && ((tieflag >> j) & 1u)) {
+                    float wv[8], bv[8];
+                    Vec8<float>::load(w_s + cc[j], wv);
+                    Vec8<float>::load(b_s + cc[j], bv);
+                    const float lv = valid[j] ? live : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float h = wv[i] * xh[j][i] + bv[i];
+                        if (h == hi) gh[j][i] += tie_hi * lv;
+                        if (h == lo) gh[j][i] += tie_lo * lv;
+                    }
+                }
+        }
+        // ---- norm backward on dL/dh = gh ----
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (j < chn) {
+                float wv[8];
+                Vec8<float>::load(w_s + cc[j], wv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    aw[j][i] += gh[j][i] * xh[j][i];
+                    ab[j][i] += gh[j][i];
+                    gh[j][i] = gh[j][i] * wv[i];
+                    s1 += gh[j][i];
+                    s2 += gh[j][i] * xh[j][i];
+                }
+            }
+        float f4[4] = {wave_sum(s1), wave_sum(s2), 0.f, 0.f};
+        if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, f4, op0);
+        const float m1 = p.ln ? f4[0] * invK : 0.f, m2 = f4[1] * invK;
+        if (livew) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (j < chn && valid[j]) {      // surplus lanes hold a masked copy of the last chunk: they must not store
+                    float o[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = (gh[j][i] - m1 - xh[j][i] * m2) * rstd;
+                    if (abase) {
+                        float ga[8];
+                        Vec8<TG>::load(abase + r * K + cc[j], ga);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[i] += ga[i];
+                    }
+                    Vec8<TG>::store(gxbase + r * K + cc[j], o);
+                }
+        }
+    }
+    // ---- column sums: waves that own the same columns (same wsub) are added in slot order, one partial row per workgroup
+    const int slab = chn * 512;
+    float* pw = p.ws + (int64_t)blockIdx.x * K;
+    float* pb = p.ws + ((int64_t)gridDim.x + blockIdx.x) * K;
+    for (int pass = 0; pass < (p.want_b ? 2 : 1); ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+            if (j < chn) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) fold[wid * slab + (j * 8 + i) * 64 + lane] = pass == 0 ? aw[j][i] : ab[j][i];
+            }
+        __syncthreads();
+        if (rslot == 0) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (j < chn && valid[j]) {
+                    float o[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float a = 0.f;
+                        for (int rs = 0; rs < rpb; ++rs) a += fold[(rs * nw + wsub) * slab + (j * 8 + i) * 64 + lane];
+                        o[i] = a;
+                    }
+                    Vec8<float>::store((pass == 0 ? pw : pb) + cc[j], o);
+                }
+        }
+    }
+}
+
 constexpr int64_t NORM_BWD_BLOCKS = 512;
 
 int norm_threads(int64_t cols) {
@@ -263,4 +583,91 @@ extern "C" int oq_norm_bwd(const void* x, const void* gy, int dtype, int64_t row
 extern "C" int64_t oq_norm_bwd_workspace(int64_t rows, int64_t cols) {
     const int64_t grid = rows < NORM_BWD_BLOCKS ? rows : NORM_BWD_BLOCKS;
     return 2 * grid * cols;
+}
+
+extern "C" int64_t oq_norm_quant_supported(int dtype, int64_t cols) {
+    RowGeo g;
+    return (dtype == OQ_BF16 || dtype == OQ_F32) && row_geo(cols, 0, &g) && cols <= 8192;
+}
+
+static int64_t normq_bwd_grid(int64_t rows, const RowGeo& g) {
+    const int rpb = g.wpb / g.nw;
+    const int64_t need = (rows + rpb - 1) / rpb;
+    const int64_t cap = env_i("OQ_NORMQ_BWD_BLOCKS", 512);
+    return need < cap ? need : cap;
+}
+
+extern "C" int64_t oq_norm_quant_bwd_workspace(int64_t rows, int64_t cols) {
+    RowGeo g;
+    if (!row_geo(cols, 0, &g)) return 0;
+    return 2 * normq_bwd_grid(rows, g) * cols;
+}
+
+extern "C" int oq_norm_quant_fwd(const void* x, int dtype, int64_t rows, int64_t cols, const float* w, const float* b, float eps,
+                                 int is_layernorm, int nbits, void* y, float* rstd, float* mean, float* scale, float* zp,
+                                 float* xmin, float* xmax, void* stream) {
+    OQ_CHECK_ARG(x && y && w && rstd && scale && zp && xmin && xmax, "oq_norm_quant_fwd: null pointer");
+    OQ_CHECK_ARG(oq_aligned16(x) && oq_aligned16(y) && oq_aligned16(w) && oq_aligned16(b), "oq_norm_quant_fwd: 16-byte alignment");
+    OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_norm_quant_fwd: rows %lld, bitwidth %d", (long long)rows, nbits);
+    OQ_CHECK_ARG(!is_layernorm || mean, "oq_norm_quant_fwd: layernorm needs the mean buffer");
+    RowGeo g;
+    if (!oq_norm_quant_supported(dtype, cols) || !row_geo(cols, 0, &g)) {
+        oq_set_error("oq_norm_quant_fwd: dtype %d / %lld columns unsupported (bf16 or f32, 512 .. 8192, multiple of 8)", dtype, (long long)cols);
+        return OQ_E_UNSUPPORTED;
+    }
+    NQ p{};
+    p.x = x; p.y = y; p.w = w; p.b = b; p.rows = rows; p.cols = cols; p.eps = eps; p.ln = is_layernorm; p.nbits = nbits;
+    p.inv_q = 1.0f / (float)((1 << nbits) - 1);
+    p.rstd = rstd; p.mean = mean; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax;
+    const int rpb = g.wpb / g.nw;
+    const int64_t need = (rows + rpb - 1) / rpb, cap = (int64_t)n_cus() * 8;
+    const dim3 grid((unsigned)(need < cap ? need : cap)), blk((unsigned)(g.wpb * 64));
+    const size_t smem = sizeof(float) * (2 * cols + 64);
+    hipStream_t st = (hipStream_t)stream;
+#define NQ_FWD(T_) do { if (g.chn <= 4) hipLaunchKernelGGL((normq_fwd_kernel<T_, T_, 4>), grid, blk, smem, st, p, g.nw, g.chn); \
+                        else hipLaunchKernelGGL((normq_fwd_kernel<T_, T_, 8>), grid, blk, smem, st, p, g.nw, g.chn); } while (0)
+    if (dtype == OQ_BF16) NQ_FWD(bf16_t); else NQ_FWD(float);
+    OQ_CHECK_LAUNCH("oq_norm_quant_fwd");
+    return OQ_OK;
+}
+
+extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, int dtype, int64_t rows, int64_t cols, const float* w,
+                                 const float* b, const float* rstd, const float* mean, int is_layernorm, int nbits,
+                                 const float* xmin, const float* xmax, void* gx, float* gw, float* gb, const void* gx_addend,
+                                 float* workspace, int64_t workspace_floats, void* stream) {
+    OQ_CHECK_ARG(x && g_ && gx && w && rstd && xmin && xmax && gw, "oq_norm_quant_bwd: null pointer");
+    OQ_CHECK_ARG(oq_aligned16(x) && oq_aligned16(g_) && oq_aligned16(gx) && oq_aligned16(w) && oq_aligned16(b) && oq_aligned16(gx_addend),
+                 "oq_norm_quant_bwd: 16-byte alignment");
+    OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_norm_quant_bwd: rows %lld, bitwidth %d", (long long)rows, nbits);
+    RowGeo g;
+    if (!oq_norm_quant_supported(dtype, cols) || !row_geo(cols, 0, &g)) {
+        oq_set_error("oq_norm_quant_bwd: dtype %d / %lld columns unsupported", dtype, (long long)cols);
+        return OQ_E_UNSUPPORTED;
+    }
+    const int64_t nblk = normq_bwd_grid(rows, g);
+    OQ_CHECK_ARG(workspace && workspace_floats >= 2 * nblk * cols, "oq_norm_quant_bwd: workspace of %lld floats needed",
+                 (long long)(2 * nblk * cols));
+    NQ p{};
+    p.x = x; p.g = g_; p.gx = gx; p.gx_add = gx_addend; p.w = w; p.b = b; p.rows = rows; p.cols = cols; p.ln = is_layernorm;
+    p.nbits = nbits; p.inv_q = 1.0f / (float)((1 << nbits) - 1);
+    p.rstd = const_cast<float*>(rstd); p.mean = const_cast<float*>(mean);
+    p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax); p.ws = workspace; p.want_b = gb ? 1 : 0;
+    const dim3 grid((unsigned)nblk), blk((unsigned)(g.wpb * 64));
+    const size_t smem = sizeof(float) * (2 * cols + 64 + (size_t)g.wpb * g.chn * 512);
+    hipStream_t st = (hipStream_t)stream;
+    if (smem > 64 * 1024) {
+        const void* k = dtype == OQ_BF16 ? (g.chn <= 4 ? (const void*)normq_bwd_kernel<bf16_t, bf16_t, 4> : (const void*)normq_bwd_kernel<bf16_t, bf16_t, 8>)
+                                         : (g.chn <= 4 ? (const void*)normq_bwd_kernel<float, float, 4> : (const void*)normq_bwd_kernel<float, float, 8>);
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+            oq_set_error("oq_norm_quant_bwd: cannot reserve %zu bytes of LDS", smem);
+            return OQ_E_LAUNCH;
+        }
+    }
+#define NQ_BWD(T_) do { if (g.chn <= 4) hipLaunchKernelGGL((normq_bwd_kernel<T_, T_, 4>), grid, blk, smem, st, p, g.nw, g.chn); \
+                        else hipLaunchKernelGGL((normq_bwd_kernel<T_, T_, 8>), grid, blk, smem, st, p, g.nw, g.chn); } while (0)
+    if (dtype == OQ_BF16) NQ_BWD(bf16_t); else NQ_BWD(float);
+    const dim3 rg((unsigned)((cols + 15) / 16), gb ? 2 : 1);
+    hipLaunchKernelGGL(norm_colreduce_kernel, rg, dim3(256), 0, st, workspace, (int)nblk, cols, gw, gb);
+    OQ_CHECK_LAUNCH("oq_norm_quant_bwd");
+    return OQ_OK;
 }

@@ -2,6 +2,7 @@
 // Everything here restates quantize/quantizer.py:84-147 arithmetic; both kernel families MUST use these functions so that
 // forward, backward and the two families agree bit for bit on scale / zero-point / rounding decisions.
 #pragma once
+#include <stdlib.h>
 #include <type_traits>
 #include "oq_common.h"
 
@@ -153,6 +154,63 @@ __device__ __forceinline__ QP make_qp(float hi, float lo, bool lwc, float up_log
     return q;
 }
 
+
+// ---- wave-per-row geometry shared by oq_rowq.hip and the fused norm + quant kernels of oq_norm.hip ------------------
+int64_t env_i(const char* n, int64_t d) {
+    const char* v = getenv(n);
+    return v ? atoll(v) : d;
+}
+
+struct RowGeo {
+    int nw;     // waves per row (1, 2, 4, 8)
+    int chn;    // 16-byte chunks per lane actually used (<= 8)
+    int wpb;    // waves per workgroup
+};
+
+// rows of 512 .. 32768 elements, multiple of 8
+bool row_geo(int64_t cols, int force_nw, RowGeo* g) {
+    if (cols % 8 != 0 || cols < 512 || cols > 32768) return false;
+    const int64_t chunks = cols / 8;
+    // two waves per row by default (4 chunks per lane, ~110 VGPRs, 4 waves per SIMD): measured better than one wave with 8
+    // chunks (175 VGPRs) on every 4096-wide kernel of the step, in-step 254.8 -> 259 sample-steps/s (tools/sweep_rowq.sh)
+    int nw = force_nw > 0 ? force_nw : (chunks >= 128 ? 2 : 1);
+    while (nw <= 8 && (chunks + 64 * nw - 1) / (64 * nw) > 8) nw <<= 1;
+    if (nw > 8 || (nw & (nw - 1))) return false;
+    g->nw = nw;
+    g->chn = (int)((chunks + 64 * nw - 1) / (64 * nw));
+    g->wpb = nw > 4 ? 8 : 4;
+    return true;
+}
+
+// cross-wave exchange of 4 per-row values among the nw waves of a row (double-buffered: one barrier per row)
+__device__ __forceinline__ void row_exchange(float* red, int& par, int wid, int rslot, int nw, int lane, float (&v)[4],
+                                             const int (&op)[4]) {
+    float* rr = red + par * 32;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rr[wid * 4 + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = op[k] == 0 ? 0.f : (op[k] == 1 ? -INFINITY : INFINITY);
+    for (int i = 0; i < nw; ++i) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(rr + (rslot * nw + i) * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = op[k] == 0 ? v[k] + q[k] : (op[k] == 1 ? fmaxf(v[k], q[k]) : fminf(v[k], q[k]));
+    }
+    par ^= 1;
+}
+
+int n_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
 
 }  // namespace
 

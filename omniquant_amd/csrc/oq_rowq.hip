@@ -24,32 +24,6 @@
 
 namespace {
 
-int64_t env_i(const char* n, int64_t d) {
-    const char* v = getenv(n);
-    return v ? atoll(v) : d;
-}
-
-struct RowGeo {
-    int nw;     // waves per row (1, 2, 4, 8)
-    int chn;    // 16-byte chunks per lane actually used (<= 8)
-    int wpb;    // waves per workgroup
-};
-
-// rows of 512 .. 32768 elements, multiple of 8
-bool row_geo(int64_t cols, int force_nw, RowGeo* g) {
-    if (cols % 8 != 0 || cols < 512 || cols > 32768) return false;
-    const int64_t chunks = cols / 8;
-    // two waves per row by default (4 chunks per lane, ~110 VGPRs, 4 waves per SIMD): measured better than one wave with 8
-    // chunks (175 VGPRs) on every 4096-wide kernel of the step, in-step 254.8 -> 259 sample-steps/s (tools/sweep_rowq.sh)
-    int nw = force_nw > 0 ? force_nw : (chunks >= 128 ? 2 : 1);
-    while (nw <= 8 && (chunks + 64 * nw - 1) / (64 * nw) > 8) nw <<= 1;
-    if (nw > 8 || (nw & (nw - 1))) return false;
-    g->nw = nw;
-    g->chn = (int)((chunks + 64 * nw - 1) / (64 * nw));
-    g->wpb = nw > 4 ? 8 : 4;
-    return true;
-}
-
 // acc[plane][chunk slot][4] += v[4 * plane .. ]: a wave's private accumulator slab, updated with plain 16-byte LDS reads
 // and writes (only the owning wave touches it, in program order: deterministic).  The two planes keep consecutive lanes on
 // consecutive 16-byte slots, which is conflict-free for ds_read_b128 / ds_write_b128.  (ds_add_f32 was tried first: one
@@ -62,25 +36,6 @@ __device__ __forceinline__ void slab_add(float* slab, int plane_stride, int slot
     b += f32x4{v[4], v[5], v[6], v[7]};
     *p0 = a;
     *p1 = b;
-}
-
-// cross-wave exchange of 4 per-row values among the nw waves of a row (double-buffered: one barrier per row)
-__device__ __forceinline__ void row_exchange(float* red, int& par, int wid, int rslot, int nw, int lane, float (&v)[4],
-                                             const int (&op)[4]) {
-    float* rr = red + par * 32;
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rr[wid * 4 + k] = v[k];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = op[k] == 0 ? 0.f : (op[k] == 1 ? -INFINITY : INFINITY);
-    for (int i = 0; i < nw; ++i) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(rr + (rslot * nw + i) * 4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = op[k] == 0 ? v[k] + q[k] : (op[k] == 1 ? fmaxf(v[k], q[k]) : fminf(v[k], q[k]));
-    }
-    par ^= 1;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -874,17 +829,6 @@ int set_smem(const void* kernel, size_t bytes) {
     if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return OQ_E_LAUNCH;
     if (n_seen < 64) { seen_k[n_seen] = kernel; seen_b[n_seen] = bytes; ++n_seen; }
     return OQ_OK;
-}
-
-int n_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
 }
 
 constexpr size_t LDS_BUDGET = 156 * 1024;

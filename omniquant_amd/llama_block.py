@@ -33,8 +33,8 @@ class QuantLlamaMLP(nn.Module):
         if hidden_act not in ("silu", "swish"):
             raise NotImplementedError(f"hidden_act {hidden_act}: only SiLU has a HIP kernel")
 
-    def forward(self, x, residual=None):
-        xq = self.gate_proj.quantize_input(x)       # gate/up share one act-quant pass (identical settings)
+    def forward(self, x, residual=None, input_is_quantized=False):
+        xq = x if input_is_quantized else self.gate_proj.quantize_input(x)   # gate/up share one act-quant pass
         gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq)
         dq = self.down_proj.act_quantizer
         if (self.down_proj.use_act_quant and dq is not None and not self.down_proj.disable_input_quant and dq.enable
@@ -116,12 +116,12 @@ class QuantLlamaAttention(nn.Module):
         return ops.rope_quant_supported(hq.dtype, self.head_dim)
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
-                output_attentions=False, use_cache=False, residual=None):
+                output_attentions=False, use_cache=False, residual=None, input_is_quantized=False):
         if past_key_value is not None or use_cache or output_attentions:
             raise NotImplementedError("the calibration hot path runs without KV cache / attention outputs")
         bsz, q_len, _ = hidden_states.size()
         nh, nkv, hd = self.num_heads, self.num_key_value_heads, self.head_dim
-        hq = self.q_proj.quantize_input(hidden_states)      # q/k/v share one act-quant pass
+        hq = hidden_states if input_is_quantized else self.q_proj.quantize_input(hidden_states)   # q/k/v share one pass
         cos, sin = self._rope_tables(position_ids, q_len, hidden_states.device)
         fused_qkv = self._fused_rope_quant(hq)
         if fused_qkv:
@@ -197,11 +197,29 @@ class QuantLlamaDecoderLayer(QuantBlockMixin, nn.Module):
                 output_attentions=False, use_cache=False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         hidden_states, back = self._enter(hidden_states)
         residual = hidden_states
-        h = self.input_layernorm(hidden_states)
+        a = self.self_attn
+        same_q = a.q_proj.act_quantizer is not None and all(
+            getattr(m.act_quantizer, "n_bits", None) == a.q_proj.act_quantizer.n_bits and m.use_act_quant == a.q_proj.use_act_quant
+            for m in (a.k_proj, a.v_proj))
+        # norm -> input quantiser of q/k/v (resp. gate/up) as ONE kernel when those quantisers are the plain dynamic
+        # per-token ones: the normalised activations are never stored (quantize/omni_norm.py + quantize/int_linear.py:59-60)
+        fq = self.input_layernorm.forward_quant(hidden_states, a.q_proj, False, self.input_layernorm.variance_epsilon) if same_q else None
+        if fq is not None:
+            h, residual = fq
+        else:
+            h = self.input_layernorm(hidden_states)
         # the two residual adds (models/int_llama_layer.py:246,264) are folded into the o_proj / down_proj GEMM stores
         hidden_states, _, _ = self.self_attn(hidden_states=h, attention_mask=attention_mask, position_ids=position_ids,
                                              past_key_value=past_key_value, output_attentions=output_attentions,
-                                             use_cache=use_cache, residual=residual)
-        h, res = self.post_attention_layernorm.forward_with_residual(hidden_states)   # residual-path grad joins in norm bwd
-        hidden_states = self.mlp(h, residual=res)
+                                             use_cache=use_cache, residual=residual, input_is_quantized=fq is not None)
+        m = self.mlp
+        same_m = m.gate_proj.act_quantizer is not None and getattr(m.up_proj.act_quantizer, "n_bits", None) == m.gate_proj.act_quantizer.n_bits \
+            and m.up_proj.use_act_quant == m.gate_proj.use_act_quant
+        fq2 = self.post_attention_layernorm.forward_quant(hidden_states, m.gate_proj, False,
+                                                          self.post_attention_layernorm.variance_epsilon) if same_m else None
+        if fq2 is not None:
+            h, res = fq2
+        else:
+            h, res = self.post_attention_layernorm.forward_with_residual(hidden_states)   # residual-path grad joins in norm bwd
+        hidden_states = self.mlp(h, residual=res, input_is_quantized=fq2 is not None)
         return (self._leave(hidden_states, back),)

@@ -4,7 +4,34 @@ import torch.nn as nn
 from . import ops
 
 
-class OmniLayerNorm(nn.Module):
+def _plain_act_quantizer(lin):
+    """The QuantLinear's input quantiser if it is the plain dynamic per-token asymmetric one main.py builds and is
+    switched on (then norm -> quant can be one kernel), else None."""
+    q = getattr(lin, "act_quantizer", None)
+    if (q is None or not lin.use_act_quant or lin.disable_input_quant or not q.enable or not (2 <= q.n_bits < 16)
+            or q.symmetric or q.lwc or q.group_size or q.metric == "fix0to1" or q.dynamic_method != "per_token"
+            or lin.__dict__.get("_stat_sink") is not None):
+        return None
+    return q
+
+
+class _FusedQuantMixin:
+    def forward_quant(self, x, lin, is_ln, eps):
+        """(fake_quant(norm(x)), x) through the fused kernels when `lin`'s input quantiser allows it, else None."""
+        q = _plain_act_quantizer(lin)
+        if q is None or not ops.norm_quant_supported(x, q.n_bits):
+            return None
+        if self.use_temporary_parameter:
+            weight, bias = self.temp_weight, self.temp_bias
+        else:
+            weight, bias = self.weight, (self.bias if hasattr(self, "bias") else None)
+        stash = {}
+        y, res = ops.NormQuantFn.apply(x, weight, bias, eps, is_ln, q.n_bits, stash)
+        q.scale, q.round_zero_point = stash["scale"], stash["zp"]
+        return y, res
+
+
+class OmniLayerNorm(_FusedQuantMixin, nn.Module):
     def __init__(self, ori_layer_norm) -> None:
         super().__init__()
         self.use_act_quant = True
@@ -37,7 +64,7 @@ class OmniLayerNorm(nn.Module):
         self.use_act_quant = use_act_quant
 
 
-class OmniLlamaRMSNorm(nn.Module):
+class OmniLlamaRMSNorm(_FusedQuantMixin, nn.Module):
     def __init__(self, ori_norm, eps=1e-6):
         super().__init__()
         self.register_buffer("weight", ori_norm.weight.detach())

@@ -484,6 +484,62 @@ class NormResidualFn(torch.autograd.Function):
         return _norm_backward(ctx, gy, gpass)
 
 
+def norm_quant_supported(x, nbits):
+    """Fused norm -> per-token fake quant (bf16 / f32, 512 .. 8192 columns).  OQ_NO_FUSED_NORMQ=1: A/B switch."""
+    if os.environ.get("OQ_NO_FUSED_NORMQ") or not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float32):
+        return False
+    return 2 <= nbits < 16 and bool(C.size_call("oq_norm_quant_supported", C._DT[x.dtype], int(x.shape[-1])))
+
+
+class NormQuantFn(torch.autograd.Function):
+    """(fake_quant_per_token(norm(x)), x): OmniLlamaRMSNorm / OmniLayerNorm (quantize/omni_norm.py:26-34,52-63) fused
+    with the act_quantizer of the QuantLinears that read its output (quantize/int_linear.py:59-60); the second output
+    hands x through for the block's residual path exactly like NormResidualFn (its gradient is added inside the backward
+    kernel).  The normalised row reaches the quantiser in fp32 and is never stored."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, is_ln, nbits, stash):
+        x = x.contiguous()
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        w32, b32 = _f32(w), _f32(b)
+        y = torch.empty_like(x)
+        rstd, scale, zp, xmin, xmax = (torch.empty((rows, 1), dtype=torch.float32, device=x.device) for _ in range(5))
+        mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if is_ln else None
+        C.call("oq_norm_quant_fwd", C.ptr(x), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), float(eps), int(is_ln), int(nbits),
+               C.ptr(y), C.fptr(rstd), C.fptr(mean), C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
+        if stash is not None:
+            stash["scale"], stash["zp"] = scale, zp
+        ctx.save_for_backward(x, w32, b32, rstd, mean, xmin, xmax)
+        ctx.cfg = (bool(is_ln), int(nbits), b is not None)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gpass):
+        x, w32, b32, rstd, mean, xmin, xmax = ctx.saved_tensors
+        is_ln, nbits, has_b = ctx.cfg
+        if gy is None:
+            return gpass, None, None, None, None, None, None
+        cols = x.shape[-1]
+        rows = x.numel() // cols
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        if gpass is not None:
+            gpass = gpass.contiguous()
+            if gpass.dtype != x.dtype:
+                gpass = gpass.to(x.dtype)
+        gx = torch.empty_like(x)
+        gw = torch.empty((cols,), dtype=torch.float32, device=x.device)
+        gb = torch.empty((cols,), dtype=torch.float32, device=x.device) if (has_b and ctx.needs_input_grad[2]) else None
+        ws_n = C.size_call("oq_norm_quant_bwd_workspace", rows, cols)
+        ws = torch.empty((ws_n,), dtype=torch.float32, device=x.device)
+        C.call("oq_norm_quant_bwd", C.ptr(x), C.ptr(gy), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), C.fptr(rstd), C.fptr(mean),
+               int(is_ln), nbits, C.fptr(xmin), C.fptr(xmax), C.ptr(gx), C.fptr(gw), C.fptr(gb), C.ptr(gpass), C.fptr(ws), ws_n,
+               C.stream())
+        return gx, (gw if ctx.needs_input_grad[1] else None), gb, None, None, None, None
+
+
 class RopeFn(torch.autograd.Function):
     """x [bs,T,heads,hd] rotated with cos/sin [T,hd] (f32, already gathered by position_ids)."""
 

@@ -442,7 +442,11 @@ class Block:
         R_ = _rounder(act_dtype)
         rnd = R_ if act_dtype is not None else None
         aq4 = act_quant and self.spec.abits < 16
-        h = R_(self._norm(x, nm["ln1"], temps))
+        # (with activation quantisation on, the product path fuses norm -> input quantiser: the norm output is not stored)
+        fused_nq = act_dtype is not None and aq4 and 512 <= H <= 8192 and H % 8 == 0
+        h = self._norm(x, nm["ln1"], temps)
+        if not fused_nq:
+            h = R_(h)
         if self.family == "llama":
             # with head-wise activation quantisation on (head_dim 128), the product path rotates and quantises the stored
             # projection output in one kernel: the rotated tensor is never stored
@@ -479,7 +483,9 @@ class Block:
                 att = F.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
                 o = R_(torch.matmul(R_(att), v).transpose(1, 2).reshape(bs, T, H))
             h = self._lin(o, nm["o"], temps, act_quant, rnd, residual=x)
-            h2 = R_(self._norm(h, nm["ln2"], temps))
+            h2 = self._norm(h, nm["ln2"], temps)
+            if not fused_nq:
+                h2 = R_(h2)
             gate = self._lin(h2, "mlp.gate_proj", temps, act_quant, rnd)
             up = self._lin(h2, "mlp.up_proj", temps, act_quant, rnd)
             act = F.silu(gate) * up

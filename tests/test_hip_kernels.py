@@ -672,3 +672,39 @@ def test_rope_quant_fused_vs_oracle(in_dtype, out_dtype, rot):
     scg = float(xo.grad.abs().max())
     assert_close(gx.float().view(bs, Tn, nh, hd) / scg, xo.grad.numpy() / scg, 2e-3 if f32 else 1e-2, 2e-4 if f32 else 6e-3, "gx",
                  max_bad_frac=0.003)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("is_ln,rows,cols", [(False, 37, 4096), (False, 20, 5120), (True, 33, 768), (False, 9, 8192), (True, 16, 1024)])
+def test_norm_quant_fused_vs_oracle(dtype, is_ln, rows, cols):
+    """y = per_token_fake_quant(norm(x)) in one kernel per direction (quantize/omni_norm.py:26-34,52-63 followed by
+    quantize/int_linear.py:59-60) vs the CPU oracle's two steps: output, dL/dx (incl. the residual-path addend), and the
+    norm weight / bias gradients (what LET's temp_weight / temp_bias receive)."""
+    from oracle import ref_cpu as R
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 2 + 0.3).to(dtype)
+    x[:, 5] *= 6
+    w = 1 + 0.2 * torch.randn(cols, generator=g)
+    b = 0.1 * torch.randn(cols, generator=g)
+    G = torch.randn(rows, cols, generator=g).to(dtype)
+    Gp = torch.randn(rows, cols, generator=g).to(dtype)
+    xo, wo, bo = x.float().clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    if is_ln:
+        h = torch.nn.functional.layer_norm(xo, (cols,), wo, bo, eps=1e-5)
+    else:
+        h = wo * (xo * torch.rsqrt(xo.pow(2).mean(-1, keepdim=True) + 1e-6)) + bo
+    yo, so, zo = R.fake_quant(h, 4, return_qparams=True)
+    ((yo * G.float()).sum() + (xo * Gp.float()).sum()).backward()
+    xd, wd, bd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    assert ops.norm_quant_supported(xd, 4)
+    stash = {}
+    yd, res = ops.NormQuantFn.apply(xd, wd, bd, 1e-5 if is_ln else 1e-6, is_ln, 4, stash)
+    f32 = dtype == torch.float32
+    step = float(so.detach().max())
+    assert_close(stash["scale"], so.detach().numpy(), 2e-5, 1e-9, "scale")
+    assert_close(yd.float(), yo.detach().numpy(), 1e-5 if f32 else 8e-3, 1e-6 if f32 else 1e-2 * step, "y", max_bad_frac=0.004)
+    ((yd.float() * G.to(DEV).float()).sum() + (res.float() * Gp.to(DEV).float()).sum()).backward()
+    for name, a, ref in (("gx", xd.grad, xo.grad), ("gw", wd.grad, wo.grad), ("gb", bd.grad, bo.grad)):
+        sc = float(ref.abs().max())
+        assert_close(a.float() / sc, ref.numpy() / sc, 3e-3 if f32 else 2e-2, 3e-4 if f32 else 8e-3, name, max_bad_frac=0.004)
