@@ -599,7 +599,7 @@ static int64_t normq_bwd_grid(int64_t rows, const RowGeo& g) {
 
 extern "C" int64_t oq_norm_quant_bwd_workspace(int64_t rows, int64_t cols) {
     RowGeo g;
-    if (!row_geo(cols, 0, &g)) return 0;
+    if (!row_geo(cols, (int)env_i("OQ_NORMQ_BWD_NW", 0), &g)) return 0;
     return 2 * normq_bwd_grid(rows, g) * cols;
 }
 
@@ -611,7 +611,7 @@ extern "C" int oq_norm_quant_fwd(const void* x, int dtype, int64_t rows, int64_t
     OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_norm_quant_fwd: rows %lld, bitwidth %d", (long long)rows, nbits);
     OQ_CHECK_ARG(!is_layernorm || mean, "oq_norm_quant_fwd: layernorm needs the mean buffer");
     RowGeo g;
-    if (!oq_norm_quant_supported(dtype, cols) || !row_geo(cols, 0, &g)) {
+    if (!oq_norm_quant_supported(dtype, cols) || !row_geo(cols, (int)env_i("OQ_NORMQ_FWD_NW", 0), &g)) {
         oq_set_error("oq_norm_quant_fwd: dtype %d / %lld columns unsupported (bf16 or f32, 512 .. 8192, multiple of 8)", dtype, (long long)cols);
         return OQ_E_UNSUPPORTED;
     }
@@ -640,7 +640,7 @@ extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, int dtype, int64
                  "oq_norm_quant_bwd: 16-byte alignment");
     OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_norm_quant_bwd: rows %lld, bitwidth %d", (long long)rows, nbits);
     RowGeo g;
-    if (!oq_norm_quant_supported(dtype, cols) || !row_geo(cols, 0, &g)) {
+    if (!oq_norm_quant_supported(dtype, cols) || !row_geo(cols, (int)env_i("OQ_NORMQ_BWD_NW", 0), &g)) {
         oq_set_error("oq_norm_quant_bwd: dtype %d / %lld columns unsupported", dtype, (long long)cols);
         return OQ_E_UNSUPPORTED;
     }
