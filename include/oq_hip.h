@@ -127,7 +127,8 @@ int oq_silu_mul_bwd(const void* gate, const void* up, const void* gy, void* ggat
  * OmniLayerNorm (1) semantics (quantize/omni_norm.py:26-34,52-63) and the dynamic per-token asymmetric quantiser of the
  * QuantLinear behind it (quantize/int_linear.py:59-60, quantize/quantizer.py:84-147).  rows x cols, cols = 512 .. 8192
  * (multiple of 8), dtype OQ_BF16 or OQ_F32 for x / y / g / gx alike; w, b (b may be NULL) f32 [cols].  The forward also
- * writes rstd, mean (layernorm) and the quantiser's scale, zp, xmin, xmax [rows]; the backward takes g = dL/dy, writes
+ * writes rstd, mean (layernorm) and the quantiser's scale, zp, xmin, xmax [rows]; the backward takes g (+ optional g2, g3:
+ * dL/dy arriving in pieces, one per consumer of y -- the q/k/v or gate/up projections -- summed in that order while loading), writes
  * gx = dL/dx (+ gx_addend, the gradient that reached x on the residual path) and the column sums gw, gb (gb may be NULL)
  * through a workspace of oq_norm_quant_bwd_workspace(rows, cols) floats (deterministic two-stage reduction). */
 int64_t oq_norm_quant_supported(int dtype, int64_t cols);
@@ -135,7 +136,8 @@ int64_t oq_norm_quant_bwd_workspace(int64_t rows, int64_t cols);
 int oq_norm_quant_fwd(const void* x, int dtype, int64_t rows, int64_t cols, const float* w, const float* b, float eps,
                       int is_layernorm, int nbits, void* y, float* rstd, float* mean, float* scale, float* zp, float* xmin,
                       float* xmax, void* stream);
-int oq_norm_quant_bwd(const void* x, const void* g, int dtype, int64_t rows, int64_t cols, const float* w, const float* b,
+int oq_norm_quant_bwd(const void* x, const void* g, const void* g2, const void* g3, int dtype, int64_t rows, int64_t cols,
+                      const float* w, const float* b,
                       const float* rstd, const float* mean, int is_layernorm, int nbits, const float* xmin, const float* xmax,
                       void* gx, float* gw, float* gb, const void* gx_addend, float* workspace, int64_t workspace_floats,
                       void* stream);

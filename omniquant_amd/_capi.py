@@ -31,7 +31,7 @@ SIGNATURES = {
     "oq_silu_mul_fwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_silu_mul_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
     "oq_norm_quant_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "oq_norm_quant_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "oq_norm_quant_bwd": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_rope_quant_fwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_rope_quant_bwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "oq_silu_mul_quant_fwd": [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],

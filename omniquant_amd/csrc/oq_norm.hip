@@ -213,6 +213,8 @@ struct NQ {
     float inv_q;
     float *rstd, *mean, *scale, *zp, *xmin, *xmax;
     const void* g;
+    const void* g2;      // optional further gradients of the same output (sibling consumers): summed while loading
+    const void* g3;
     void* gx;
     const void* gx_add;
     float* ws;
@@ -377,6 +379,8 @@ __global__ void __launch_bounds__(512) normq_bwd_kernel(NQ p, int nw, int chn) {
     }
     const TIN* xbase = reinterpret_cast<const TIN*>(p.x);
     const TG* gbase = reinterpret_cast<const TG*>(p.g);
+    const TG* g2base = reinterpret_cast<const TG*>(p.g2);
+    const TG* g3base = reinterpret_cast<const TG*>(p.g3);
     const TG* abase = reinterpret_cast<const TG*>(p.gx_add);
     TG* gxbase = reinterpret_cast<TG*>(p.gx);
     const float invK = 1.f / (float)K;
@@ -401,6 +405,18 @@ __global__ void __launch_bounds__(512) normq_bwd_kernel(NQ p, int nw, int chn) {
                 float G[8], wv[8], bv[8];
                 Vec8<TIN>::load(xbase + r * K + cc[j], xh[j]);
                 Vec8<TG>::load(gbase + r * K + cc[j], G);
+                if (g2base) {       // dL/dy arrives in pieces (one per consumer of y): added here, in a fixed order
+                    float G2[8];
+                    Vec8<TG>::load(g2base + r * K + cc[j], G2);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) G[i] += G2[i];
+                }
+                if (g3base) {
+                    float G3[8];
+                    Vec8<TG>::load(g3base + r * K + cc[j], G3);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) G[i] += G3[i];
+                }
                 Vec8<float>::load(w_s + cc[j], wv);
                 Vec8<float>::load(b_s + cc[j], bv);
                 const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
@@ -631,7 +647,7 @@ extern "C" int oq_norm_quant_fwd(const void* x, int dtype, int64_t rows, int64_t
     return OQ_OK;
 }
 
-extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, int dtype, int64_t rows, int64_t cols, const float* w,
+extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, const void* g2, const void* g3, int dtype, int64_t rows, int64_t cols, const float* w,
                                  const float* b, const float* rstd, const float* mean, int is_layernorm, int nbits,
                                  const float* xmin, const float* xmax, void* gx, float* gw, float* gb, const void* gx_addend,
                                  float* workspace, int64_t workspace_floats, void* stream) {
@@ -648,7 +664,8 @@ extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, int dtype, int64
     OQ_CHECK_ARG(workspace && workspace_floats >= 2 * nblk * cols, "oq_norm_quant_bwd: workspace of %lld floats needed",
                  (long long)(2 * nblk * cols));
     NQ p{};
-    p.x = x; p.g = g_; p.gx = gx; p.gx_add = gx_addend; p.w = w; p.b = b; p.rows = rows; p.cols = cols; p.ln = is_layernorm;
+    OQ_CHECK_ARG(oq_aligned16(g2) && oq_aligned16(g3) && (g2 || !g3), "oq_norm_quant_bwd: g2 / g3 alignment (g3 needs g2)");
+    p.x = x; p.g = g_; p.g2 = g2; p.g3 = g3; p.gx = gx; p.gx_add = gx_addend; p.w = w; p.b = b; p.rows = rows; p.cols = cols; p.ln = is_layernorm;
     p.nbits = nbits; p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.rstd = const_cast<float*>(rstd); p.mean = const_cast<float*>(mean);
     p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax); p.ws = workspace; p.want_b = gb ? 1 : 0;

@@ -8,10 +8,10 @@ from . import ops
 from .quantizer import UniformAffineQuantizer
 
 
-def _hip_linear(input, weight, bias=None, residual=None):
+def _hip_linear(input, weight, bias=None, residual=None, sib=None):
     if weight.dtype != input.dtype:
         weight = ops.cast(weight, input.dtype)
-    return ops.LinearFn.apply(input, weight, bias, residual)
+    return ops.LinearFn.apply(input, weight, bias, residual, sib)
 
 
 class QuantLinear(nn.Module):
@@ -84,20 +84,23 @@ class QuantLinear(nn.Module):
             return self.weight_quantizer.quantize(self.weight, out_dtype=dtype), self.bias
         return self._weight_as(dtype), self.bias
 
-    def forward(self, input: torch.Tensor, input_is_quantized: bool = False, residual=None):
-        """residual (HIP-path extension): added to the output inside the GEMM's store (the block's residual add)."""
+    def forward(self, input: torch.Tensor, input_is_quantized: bool = False, residual=None, sib=None):
+        """residual (HIP-path extension): added to the output inside the GEMM's store (the block's residual add).
+        sib: ops.SiblingGrads collector of the tensor `input` came from (fused norm -> quant), or None."""
         sink = self.__dict__.get("_stat_sink")
         if sink is not None:                        # LET-init statistics ride on the FP teacher pass (actstats.py)
             sink[0].update(sink[1], input)
         weight, bias = self._resolve(input.dtype)
         if not input_is_quantized:
             input = self.quantize_input(input)
+        if sib is not None and self.fwd_func is _hip_linear:
+            return self.fwd_func(input, weight, bias, residual=residual, sib=sib, **self.fwd_kwargs)
         if residual is not None:
             return self.fwd_func(input, weight, bias, residual=residual, **self.fwd_kwargs)
         return self.fwd_func(input, weight, bias, **self.fwd_kwargs)
 
     @staticmethod
-    def forward_siblings(mods, input):
+    def forward_siblings(mods, input, sib=None):
         """Projections reading the SAME (already act-quantised) input: one autograd node whose backward accumulates
         the input gradient in the dgrad GEMMs' epilogue (ops.SiblingLinearFn).  Falls back to independent calls when a
         module does not use the HIP GEMM as its fwd_func."""
@@ -105,7 +108,7 @@ class QuantLinear(nn.Module):
         # step (same-box A/B 245.9 vs 248.6 sample-steps/s): the epilogue's read-modify-write of the 16.8 MB gradient
         # costs more inside the MFMA kernel than in a streaming add
         if os.environ.get("OQ_SIBLING", "0") == "0" or any(m.fwd_func is not _hip_linear or m.fwd_kwargs for m in mods):
-            return tuple(m(input, True) for m in mods)
+            return tuple(m(input, True, sib=sib) for m in mods)
         wb = []
         for m in mods:
             sink = m.__dict__.get("_stat_sink")

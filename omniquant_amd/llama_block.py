@@ -33,9 +33,9 @@ class QuantLlamaMLP(nn.Module):
         if hidden_act not in ("silu", "swish"):
             raise NotImplementedError(f"hidden_act {hidden_act}: only SiLU has a HIP kernel")
 
-    def forward(self, x, residual=None, input_is_quantized=False):
+    def forward(self, x, residual=None, input_is_quantized=False, sib=None):
         xq = x if input_is_quantized else self.gate_proj.quantize_input(x)   # gate/up share one act-quant pass
-        gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq)
+        gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq, sib)
         dq = self.down_proj.act_quantizer
         if (self.down_proj.use_act_quant and dq is not None and not self.down_proj.disable_input_quant and dq.enable
                 and dq.n_bits < 16 and not dq.symmetric and dq.metric != "fix0to1" and not dq.group_size
@@ -116,7 +116,7 @@ class QuantLlamaAttention(nn.Module):
         return ops.rope_quant_supported(hq.dtype, self.head_dim)
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
-                output_attentions=False, use_cache=False, residual=None, input_is_quantized=False):
+                output_attentions=False, use_cache=False, residual=None, input_is_quantized=False, sib=None):
         if past_key_value is not None or use_cache or output_attentions:
             raise NotImplementedError("the calibration hot path runs without KV cache / attention outputs")
         bsz, q_len, _ = hidden_states.size()
@@ -133,11 +133,11 @@ class QuantLlamaAttention(nn.Module):
                 if w.dtype != hq.dtype:
                     w = ops.cast(w, hq.dtype)
                 stash = {}
-                outs.append(ops.LinearRopeQuantFn.apply(hq, w, b, cos if rot else None, sin if rot else None, qz.n_bits, hd, stash))
+                outs.append(ops.LinearRopeQuantFn.apply(hq, w, b, cos if rot else None, sin if rot else None, qz.n_bits, hd, stash, sib))
                 qz.scale, qz.round_zero_point = stash["scale"], stash["zp"]
             q, k, v = outs
         else:
-            q, k, v = QuantLinear.forward_siblings([self.q_proj, self.k_proj, self.v_proj], hq)
+            q, k, v = QuantLinear.forward_siblings([self.q_proj, self.k_proj, self.v_proj], hq, sib)
             q, k, v = q.view(bsz, q_len, nh, hd), k.view(bsz, q_len, nkv, hd), v.view(bsz, q_len, nkv, hd)
             q = ops.RopeFn.apply(q, cos, sin)
             k = ops.RopeFn.apply(k, cos, sin)
@@ -204,22 +204,23 @@ class QuantLlamaDecoderLayer(QuantBlockMixin, nn.Module):
         # norm -> input quantiser of q/k/v (resp. gate/up) as ONE kernel when those quantisers are the plain dynamic
         # per-token ones: the normalised activations are never stored (quantize/omni_norm.py + quantize/int_linear.py:59-60)
         fq = self.input_layernorm.forward_quant(hidden_states, a.q_proj, False, self.input_layernorm.variance_epsilon) if same_q else None
+        sib1 = sib2 = None
         if fq is not None:
-            h, residual = fq
+            h, residual, sib1 = fq
         else:
             h = self.input_layernorm(hidden_states)
         # the two residual adds (models/int_llama_layer.py:246,264) are folded into the o_proj / down_proj GEMM stores
         hidden_states, _, _ = self.self_attn(hidden_states=h, attention_mask=attention_mask, position_ids=position_ids,
                                              past_key_value=past_key_value, output_attentions=output_attentions,
-                                             use_cache=use_cache, residual=residual, input_is_quantized=fq is not None)
+                                             use_cache=use_cache, residual=residual, input_is_quantized=fq is not None, sib=sib1)
         m = self.mlp
         same_m = m.gate_proj.act_quantizer is not None and getattr(m.up_proj.act_quantizer, "n_bits", None) == m.gate_proj.act_quantizer.n_bits \
             and m.up_proj.use_act_quant == m.gate_proj.use_act_quant
         fq2 = self.post_attention_layernorm.forward_quant(hidden_states, m.gate_proj, False,
                                                           self.post_attention_layernorm.variance_epsilon) if same_m else None
         if fq2 is not None:
-            h, res = fq2
+            h, res, sib2 = fq2
         else:
             h, res = self.post_attention_layernorm.forward_with_residual(hidden_states)   # residual-path grad joins in norm bwd
-        hidden_states = self.mlp(h, residual=res, input_is_quantized=fq2 is not None)
+        hidden_states = self.mlp(h, residual=res, input_is_quantized=fq2 is not None, sib=sib2)
         return (self._leave(hidden_states, back),)

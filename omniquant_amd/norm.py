@@ -17,7 +17,8 @@ def _plain_act_quantizer(lin):
 
 class _FusedQuantMixin:
     def forward_quant(self, x, lin, is_ln, eps):
-        """(fake_quant(norm(x)), x) through the fused kernels when `lin`'s input quantiser allows it, else None."""
+        """(fake_quant(norm(x)), x, sibling-gradient collector) through the fused kernels when `lin`'s input quantiser
+        allows it, else None.  The collector (ops.SiblingGrads, may be None) is to be handed to every consumer of y."""
         q = _plain_act_quantizer(lin)
         if q is None or not ops.norm_quant_supported(x, q.n_bits):
             return None
@@ -28,7 +29,7 @@ class _FusedQuantMixin:
         stash = {}
         y, res = ops.NormQuantFn.apply(x, weight, bias, eps, is_ln, q.n_bits, stash)
         q.scale, q.round_zero_point = stash["scale"], stash["zp"]
-        return y, res
+        return y, res, stash.get("sib")
 
 
 class OmniLayerNorm(_FusedQuantMixin, nn.Module):

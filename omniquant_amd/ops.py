@@ -159,12 +159,35 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, a_kc, b_kc, bias=None, alpha=1.0, batc
            batch_o, batch_i, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], int(tri), C.stream())
 
 
+class SiblingGrads:
+    """Side channel for the input gradient of SIBLING consumers of one tensor (q/k/v projections; gate/up): the first
+    consumer whose backward runs returns its dL/dx to autograd as usual, the others park theirs here and return None, and
+    the producer's backward kernel (oq_norm_quant_bwd) adds the parked pieces while it loads the gradient -- instead of
+    autograd materialising the sum with one `add` launch per extra consumer (3 launches, 100 MB of traffic per step)."""
+
+    def __init__(self):
+        self.primary = False
+        self.parts = []
+
+    def offer(self, gx):
+        if not self.primary:
+            self.primary = True
+            return gx
+        self.parts.append(gx)
+        return None
+
+    def take(self):
+        parts, self.parts, self.primary = self.parts, [], False
+        return parts
+
+
 class LinearFn(torch.autograd.Function):
     """y = x @ wq.T + bias (+ residual)  (quantize/int_linear.py:62; the residual add of
     models/int_llama_layer.py:246,264 is folded into the GEMM's store) with dgrad / wgrad / bias-grad kernels."""
 
     @staticmethod
-    def forward(ctx, x, wq, bias, residual=None):
+    def forward(ctx, x, wq, bias, residual=None, sib=None):
+        ctx.sib = sib
         x2 = x.contiguous().view(-1, x.shape[-1])
         wq = wq.contiguous()
         T, K = x2.shape
@@ -197,6 +220,8 @@ class LinearFn(torch.autograd.Function):
             # dX[t,k] = sum_n dY[t,n] * W[n,k]   (B is k-strided: B(k_out, n) = W[n*K + k_out])
             gemm(gy2, wq, gx, T, K, N, N, K, K, True, False)
             gx = gx.view(ctx.xshape)
+            if ctx.sib is not None:
+                gx = ctx.sib.offer(gx)
         if ctx.needs_input_grad[1]:
             gw = torch.empty((N, K), dtype=wq.dtype, device=x2.device)
             # dW[n,k] = sum_t dY[t,n] * X[t,k]   (both operands k-strided)
@@ -207,7 +232,7 @@ class LinearFn(torch.autograd.Function):
             ws = torch.empty(ws_n, dtype=torch.float32, device=gy2.device)
             C.call("oq_colsum", C.ptr(gy2), C.dt(gy2), T, N, C.fptr(gb), C.fptr(ws), ws_n, C.stream())
         gres = gy if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres
+        return gx, gw, gb, gres, None
 
 
 def rope_quant_supported(dtype, hd):
@@ -227,7 +252,8 @@ class LinearRopeQuantFn(torch.autograd.Function):
     x [bs, T, K]; returns y [bs, T, nh, hd]."""
 
     @staticmethod
-    def forward(ctx, x, wq, bias, cos, sin, nbits, hd, stash):
+    def forward(ctx, x, wq, bias, cos, sin, nbits, hd, stash, sib=None):
+        ctx.sib = sib
         x2 = x.contiguous().view(-1, x.shape[-1])
         wq = wq.contiguous()
         rows, K = x2.shape
@@ -266,6 +292,8 @@ class LinearRopeQuantFn(torch.autograd.Function):
             gx = torch.empty((rows, K), dtype=x2.dtype, device=x2.device)
             gemm(gpre, wq, gx, rows, K, N, N, K, K, True, False)
             gx = gx.view(xshape)
+            if ctx.sib is not None:
+                gx = ctx.sib.offer(gx)
         if ctx.needs_input_grad[1]:
             gw = torch.empty((N, K), dtype=wq.dtype, device=x2.device)
             gemm(gpre, x2, gw, N, K, rows, N, K, K, False, False)
@@ -274,7 +302,7 @@ class LinearRopeQuantFn(torch.autograd.Function):
             ws_n = C.size_call("oq_colsum_workspace", rows, N)
             ws = torch.empty(ws_n, dtype=torch.float32, device=x2.device)
             C.call("oq_colsum", C.ptr(gpre), C.dt(gpre), rows, N, C.fptr(gb), C.fptr(ws), ws_n, C.stream())
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 class SiblingLinearFn(torch.autograd.Function):
@@ -508,8 +536,11 @@ class NormQuantFn(torch.autograd.Function):
         mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if is_ln else None
         C.call("oq_norm_quant_fwd", C.ptr(x), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), float(eps), int(is_ln), int(nbits),
                C.ptr(y), C.fptr(rstd), C.fptr(mean), C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
+        ctx.sib = None
         if stash is not None:
             stash["scale"], stash["zp"] = scale, zp
+            if not os.environ.get("OQ_NO_SIBLING_GRADS"):
+                ctx.sib = stash["sib"] = SiblingGrads()       # hand this to every consumer of y (see SiblingGrads)
         ctx.save_for_backward(x, w32, b32, rstd, mean, xmin, xmax)
         ctx.cfg = (bool(is_ln), int(nbits), b is not None)
         return y, x.view_as(x)
@@ -529,12 +560,19 @@ class NormQuantFn(torch.autograd.Function):
             gpass = gpass.contiguous()
             if gpass.dtype != x.dtype:
                 gpass = gpass.to(x.dtype)
+        parts = ctx.sib.take() if ctx.sib is not None else []
+        parts = [t.contiguous().view(rows, cols) for t in parts]
+        if any(t.dtype != x.dtype for t in parts) or len(parts) > 2:
+            gy = gy + sum(t.to(x.dtype) for t in parts)            # more pieces than the kernel takes: plain adds
+            parts = []
+        g2 = parts[0] if len(parts) > 0 else None
+        g3 = parts[1] if len(parts) > 1 else None
         gx = torch.empty_like(x)
         gw = torch.empty((cols,), dtype=torch.float32, device=x.device)
         gb = torch.empty((cols,), dtype=torch.float32, device=x.device) if (has_b and ctx.needs_input_grad[2]) else None
         ws_n = C.size_call("oq_norm_quant_bwd_workspace", rows, cols)
         ws = torch.empty((ws_n,), dtype=torch.float32, device=x.device)
-        C.call("oq_norm_quant_bwd", C.ptr(x), C.ptr(gy), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), C.fptr(rstd), C.fptr(mean),
+        C.call("oq_norm_quant_bwd", C.ptr(x), C.ptr(gy), C.ptr(g2), C.ptr(g3), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), C.fptr(rstd), C.fptr(mean),
                int(is_ln), nbits, C.fptr(xmin), C.fptr(xmax), C.ptr(gx), C.fptr(gw), C.fptr(gb), C.ptr(gpass), C.fptr(ws), ws_n,
                C.stream())
         return gx, (gw if ctx.needs_input_grad[1] else None), gb, None, None, None, None

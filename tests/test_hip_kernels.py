@@ -708,3 +708,39 @@ def test_norm_quant_fused_vs_oracle(dtype, is_ln, rows, cols):
     for name, a, ref in (("gx", xd.grad, xo.grad), ("gw", wd.grad, wo.grad), ("gb", bd.grad, bo.grad)):
         sc = float(ref.abs().max())
         assert_close(a.float() / sc, ref.numpy() / sc, 3e-3 if f32 else 2e-2, 3e-4 if f32 else 8e-3, name, max_bad_frac=0.004)
+
+
+def test_sibling_gradients_are_summed_inside_the_norm_backward():
+    """Three projections read one fused norm -> quant output: with the SiblingGrads side channel only the first consumer's
+    input gradient goes through autograd, the other two are added inside oq_norm_quant_bwd.  Must equal autograd's own
+    accumulation (OQ_NO_SIBLING_GRADS=1) up to fp32 summation order."""
+    import os
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows, K, N = 48, 1024, 256
+    x = torch.randn(rows, K, generator=g)
+    w = 1 + 0.1 * torch.randn(K, generator=g)
+    Ws = [torch.randn(N, K, generator=g) * 0.05 for _ in range(3)]
+    Gs = [torch.randn(rows, N, generator=g) for _ in range(3)]
+
+    def run():
+        xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+        stash = {}
+        y, res = ops.NormQuantFn.apply(xd, wd, None, 1e-6, False, 4, stash)
+        sib = stash.get("sib")
+        tot = res.sum() * 0.01
+        for W_, G_ in zip(Ws, Gs):
+            tot = tot + (ops.LinearFn.apply(y, W_.to(DEV), None, None, sib) * G_.to(DEV)).sum()
+        tot.backward()
+        return xd.grad.clone(), wd.grad.clone(), sib
+
+    gx1, gw1, sib = run()
+    assert sib is not None and sib.parts == [] and not sib.primary          # consumed by the norm backward
+    os.environ["OQ_NO_SIBLING_GRADS"] = "1"
+    try:
+        gx0, gw0, sib0 = run()
+    finally:
+        del os.environ["OQ_NO_SIBLING_GRADS"]
+    assert sib0 is None
+    assert float((gx1 - gx0).abs().max()) <= 1e-5 * float(gx0.abs().max())
+    assert float((gw1 - gw0).abs().max()) <= 1e-5 * float(gw0.abs().max())
