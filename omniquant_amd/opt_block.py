@@ -38,13 +38,13 @@ class QuantOPTAttention(nn.Module):
         self.use_act_quant = False
 
     def forward(self, hidden_states, key_value_states=None, past_key_value=None, attention_mask=None,
-                layer_head_mask=None, output_attentions=False, residual=None):
+                layer_head_mask=None, output_attentions=False, residual=None, input_is_quantized=False, sib=None):
         if key_value_states is not None or past_key_value is not None or layer_head_mask is not None or output_attentions:
             raise NotImplementedError("the calibration hot path runs self-attention without cache / head masks")
         bsz, tgt_len, _ = hidden_states.size()
         nh, hd = self.num_heads, self.head_dim
-        hq = self.q_proj.quantize_input(hidden_states)      # q/k/v share one act-quant pass
-        q, k, v = QuantLinear.forward_siblings([self.q_proj, self.k_proj, self.v_proj], hq)
+        hq = hidden_states if input_is_quantized else self.q_proj.quantize_input(hidden_states)   # q/k/v share one pass
+        q, k, v = QuantLinear.forward_siblings([self.q_proj, self.k_proj, self.v_proj], hq, sib)
         q = self.qkt_matmul.quant_x1(ops.ScaleFn.apply(q, self.scaling))
         k = self.qkt_matmul.quant_x2(k)
         v = self.pv_matmul.quant_x2(v)
@@ -98,17 +98,35 @@ class QuantOPTDecoderLayer(QuantBlockMixin, nn.Module):
             raise NotImplementedError("the calibration hot path runs without KV cache / attention outputs")
         hidden_states, back = self._enter(hidden_states)
         residual = hidden_states
-        h = self.self_attn_layer_norm(hidden_states) if self.do_layer_norm_before else hidden_states
+        a = self.self_attn
+        fq = None
+        if self.do_layer_norm_before:
+            same = a.q_proj.act_quantizer is not None and all(
+                getattr(m.act_quantizer, "n_bits", None) == a.q_proj.act_quantizer.n_bits and m.use_act_quant == a.q_proj.use_act_quant
+                for m in (a.k_proj, a.v_proj))
+            # LayerNorm -> input quantiser of q/k/v as one kernel when it is the plain dynamic per-token one (llama_block.py)
+            fq = self.self_attn_layer_norm.forward_quant(hidden_states, a.q_proj, True, self.self_attn_layer_norm.eps) if same else None
+        sib1 = sib2 = None
+        if fq is not None:
+            h, residual, sib1 = fq
+        else:
+            h = self.self_attn_layer_norm(hidden_states) if self.do_layer_norm_before else hidden_states
         hidden_states, _, _ = self.self_attn(hidden_states=h, past_key_value=past_key_value, attention_mask=attention_mask,
                                              layer_head_mask=layer_head_mask, output_attentions=output_attentions,
-                                             residual=residual)      # residual add folded into out_proj's GEMM store
+                                             residual=residual, input_is_quantized=fq is not None,
+                                             sib=sib1)      # residual add folded into out_proj's GEMM store
         if not self.do_layer_norm_before:
             hidden_states = self.self_attn_layer_norm(hidden_states)
+        fq2 = None
         if self.do_layer_norm_before:
-            h, residual = self.final_layer_norm.forward_with_residual(hidden_states)    # residual-path grad joins in norm bwd
+            fq2 = self.final_layer_norm.forward_quant(hidden_states, self.fc1, True, self.final_layer_norm.eps)
+            if fq2 is not None:
+                h, residual, sib2 = fq2
+            else:
+                h, residual = self.final_layer_norm.forward_with_residual(hidden_states)    # residual-path grad joins in norm bwd
         else:
             h = residual = hidden_states
-        hidden_states = self.fc2(ops.ReluFn.apply(self.fc1(h)), residual=residual)
+        hidden_states = self.fc2(ops.ReluFn.apply(self.fc1(h, fq2 is not None, sib=sib2)), residual=residual)
         if not self.do_layer_norm_before:
             hidden_states = self.final_layer_norm(hidden_states)
         return (self._leave(hidden_states, back),)

@@ -272,3 +272,59 @@ def test_w16_weights_pass_through_with_let_vs_oracle():
     q.smooth_and_quant_inplace()
     q.register_scales_and_zeros()
     assert q.mlp.down_proj.weight_quantizer.scales is None
+
+
+def test_opt_block_w4a4_let_at_opt125m_width_vs_oracle():
+    """OPT decoder block at OPT-125m width (768 / 3072 / 12 heads), W4A4 + LET, fp32 parity mode: here the LayerNorm ->
+    input-quantiser pairs run the fused oq_norm_quant kernels (hidden >= 512) with the sibling-gradient side channel.
+    One sample-step vs the CPU oracle: loss and every LWC / LET gradient."""
+    from oracle import ref_cpu as R
+    from omniquant_amd.calibrate import default_args, register_let_parameters
+    from omniquant_amd.synthetic import make_config, make_layer, make_calib_inputs, causal_mask, synth_act_stats
+    from omniquant_amd.opt_block import QuantOPTDecoderLayer
+    from omniquant_amd import ops
+    cfg = make_config("opt-125m")
+    args = default_args(wbits=4, abits=4, lwc=True, let=True, epochs=1, nsamples=1, net="opt-125m")
+    layer = make_layer(cfg, seed=4, device=DEV)
+    weights = {n: p.detach().float().cpu() for n, p in layer.named_parameters()}
+    q = QuantOPTDecoderLayer(cfg, layer, args).to(DEV)
+    q.compute_dtype = torch.float32
+    q.set_quant_state(False, True)
+    q.let = True
+    sc, sh = synth_act_stats(cfg, 1)
+    register_let_parameters(q, "opt", sc, sh, 0.5, 0, DEV)
+    with torch.no_grad():
+        for p_ in q.parameters():
+            p_.data = p_.data.float()
+    T = 64
+    x = make_calib_inputs(1, T, 768, dtype=torch.float32)
+    tgt = make_calib_inputs(1, T, 768, seed=9, dtype=torch.float32)
+    mask = causal_mask(T)
+    cd = dict(hidden_size=768, num_attention_heads=12)
+    blk = R.Block("opt", cd, weights, R.QuantSpec(4, 4, None, True, True), max_pos=T)
+    blk.register_let(sc, sh, 0.5, 0, "model.decoder.layers")
+    out_o = blk.forward(x, mask, None, temps=blk.temporaries(), act_quant=True)
+    loss_o = torch.nn.functional.mse_loss(tgt, out_o)
+    loss_o.backward()
+    calls = {"n": 0}
+    orig = ops.NormQuantFn.apply
+
+    class _Spy:
+        @staticmethod
+        def apply(*a):
+            calls["n"] += 1
+            return orig(*a)
+    ops.NormQuantFn, keep = _Spy, ops.NormQuantFn
+    try:
+        q.smooth_and_quant_temporary()
+        out = q(x.to(DEV), attention_mask=mask.to(DEV))[0]
+        loss = torch.nn.functional.mse_loss(tgt.to(DEV), out)
+        loss.backward()
+    finally:
+        ops.NormQuantFn = keep
+    assert calls["n"] == 2, "both LayerNorm -> quantiser pairs must take the fused kernels"
+    assert abs(float(loss) - float(loss_o)) <= 2e-3 * float(loss_o)
+    for n, p_ in q.named_parameters():
+        ref = blk.params[n].grad
+        rel = float((p_.grad.cpu() - ref).norm()) / (float(ref.norm()) + 1e-20)
+        assert rel < 3e-2, (n, rel)          # a few 4-bit activation rounding ties may flip between the two fp32 runs
