@@ -604,11 +604,13 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_FWD_WPE : 2) letq_fwd_kern
     }
 }
 
-template <typename TIN, typename TG, int CH>
+// MODE: bit 0 = row_div present, bit 1 = row_mul present (compile-time: the element loop carries no selects for them)
+template <typename TIN, typename TG, int CH, int MODE>
 __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kernel(FQ p) {
     __shared__ __attribute__((aligned(16))) float part[4][RG][4];
     __shared__ __attribute__((aligned(16))) float qps2[2][RG][12];    // by group parity: phase A of the next group overlaps phase D
     __shared__ __attribute__((aligned(16))) float ties[RG][4];
+    constexpr bool has_rd = (MODE & 1) != 0, has_rm = (MODE & 2) != 0;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int K = (int)p.cols;
@@ -617,7 +619,6 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
     const bool need_cm = p.g_col_mul != nullptr, need_sh = p.g_shift != nullptr;
     const bool need_row = p.g_row_div || p.g_row_mul;
     const bool ident = p.nbits >= 16;
-    const bool has_rd = p.row_div != nullptr, has_rm = p.row_mul != nullptr;
     bool valid[CH];
     int cc[CH];
     float cm[CH][8], acc_cm[CH][8], acc_sh[CH][8];
@@ -635,19 +636,31 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
     const bool lwc = p.up != nullptr;
     const int64_t ngroups = (p.rows + RG - 1) / RG;
     int par = 0;
+    // the rows a workgroup walks form one stream: while row t is processed rows t+1 and t+2 are in flight, across group
+    // boundaries too (the next group's first rows load under phases C, D and A); three rows of raw vectors live at a time
+    auto stream_row = [&](int64_t g, int k) -> int64_t {
+        const int64_t r = k < RG ? g * RG + k : (g + gridDim.x) * RG + (k - RG);
+        return r < p.rows ? r : p.rows - 1;        // past the end: a re-read of the last row nobody uses
+    };
+    Raw8<TIN> cw[CH], n1w[CH];
+    Raw8<TG> cg[CH], n1g[CH];
+    if ((int64_t)blockIdx.x < ngroups) {
+        const int64_t ra = stream_row(blockIdx.x, 0), rb = stream_row(blockIdx.x, 1);
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            cw[j].load(wbase + ra * K + cc[j]);
+            cg[j].load(gbase + ra * K + cc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            n1w[j].load(wbase + rb * K + cc[j]);
+            n1g[j].load(gbase + rb * K + cc[j]);
+        }
+    }
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x, par ^= 1) {
         const int64_t r0 = g * RG;
         float (*qps)[12] = qps2[par];
         auto row_of = [&](int rr) { return r0 + rr < p.rows ? r0 + rr : p.rows - 1; };
-        // the first row's chunks are in flight under phase A; inside phase B row rr+1 is loaded while row rr is processed
-        // (two rows of raw vectors live at a time: keeps the kernel near 128 VGPRs instead of 300)
-        Raw8<TIN> cw[CH];
-        Raw8<TG> cg[CH];
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            cw[j].load(wbase + row_of(0) * K + cc[j]);
-            cg[j].load(gbase + row_of(0) * K + cc[j]);
-        }
         // ---- phase A: wave w prepares the constants of row w ---------------------------------------------------------
         QP q;                       // kept by the finalising wave for phase C
         float my_rm = 1.f, my_rmrd = 1.f;
@@ -660,14 +673,16 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
             const float inv_rd = 1.f / rd;
             float inv_s = 0.f;
             q = make_qp(hi, lo, lwc, lwc ? p.up[r] : 0.f, lwc ? p.low[r] : 0.f, p.nbits, p.symmetric, p.inv_q, &inv_s);
-            const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f;
+            // scale == 0 (quirk Q1): the reference's round_ste turns x / 0 = +-inf into NaN; a NaN zero-point inside
+            // round(t) + z gives the same all-NaN row without a per-element select ((r - t) + t == r for every finite t)
+            const float zr = q.s == 0.f ? NAN : q.z;
             my_rm = rm;
             my_rmrd = rm * inv_rd;
             if (lane == 0) {
                 float* d = &qps[wid][0];
-                *reinterpret_cast<f32x4*>(d) = f32x4{q.s, q.z, inv_s, regular ? 1.f : 0.f};
+                *reinterpret_cast<f32x4*>(d) = f32x4{q.s, q.z, inv_s, zr};
                 *reinterpret_cast<f32x4*>(d + 4) = f32x4{hi, lo, rd, rm};
-                *reinterpret_cast<f32x4*>(d + 8) = f32x4{inv_rd, rm * inv_rd, gws, r0 + wid < p.rows ? 1.f : 0.f};
+                *reinterpret_cast<f32x4*>(d + 8) = f32x4{inv_rd, rm * inv_rd, gws, 0.f};
             }
         }
         __syncthreads();
@@ -675,64 +690,75 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
         uint32_t tieflag = 0;               // bit rr*CH + j
 #pragma unroll 1                            // a real loop: unrolled, the four rows' constants and vectors cost 260+ VGPRs
         for (int rr = 0; rr < RG; ++rr) {
-            const f32x4 qa = *reinterpret_cast<const f32x4*>(&qps[rr][0]);
-            const f32x4 qb = *reinterpret_cast<const f32x4*>(&qps[rr][4]);
-            const f32x4 qc = *reinterpret_cast<const f32x4*>(&qps[rr][8]);
-            const float z = qa[1], inv_s = qa[2], hi = qb[0], lo = qb[1], rd = qb[2], rm = qb[3];
-            const float inv_rd = qc[0], rmrd = qc[1], gws = qc[2] * qc[3], rowlive = qc[3];
-            const bool regular = qa[3] != 0.f;
-            float gs = 0.f, arm = 0.f;
-            int whi = 0, wlo = 0;
             Raw8<TIN> nw_[CH];
             Raw8<TG> ng_[CH];
-            if (rr + 1 < RG) {
+            {
+                const int64_t rn = stream_row(g, rr + 2);
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
-                    nw_[j].load(wbase + row_of(rr + 1) * K + cc[j]);
-                    ng_[j].load(gbase + row_of(rr + 1) * K + cc[j]);
+                    nw_[j].load(wbase + rn * K + cc[j]);
+                    ng_[j].load(gbase + rn * K + cc[j]);
                 }
             }
-            // (a separate select-free copy of this loop for the regular case was tried: it pushed the kernel over 168 VGPRs,
-            //  spilled, and ran 25 % slower)
+            float gs = 0.f, arm = 0.f;
+            int whi = 0, wlo = 0;
+            if (r0 + rr < p.rows) {          // rows past the end of a short last group add nothing (uniform branch)
+                const f32x4 qa = *reinterpret_cast<const f32x4*>(&qps[rr][0]);
+                const f32x4 qb = *reinterpret_cast<const f32x4*>(&qps[rr][4]);
+                const f32x4 qc = *reinterpret_cast<const f32x4*>(&qps[rr][8]);
+                const float z = qa[1], inv_s = qa[2], zr = qa[3], hi = qb[0], lo = qb[1], rd = qb[2], rm = qb[3];
+                const float inv_rd = qc[0], rmrd = qc[1], gws = qc[2];
 #pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                float w[8], G[8];
-                cw[j].unpack(w);
-                cg[j].unpack(G);
-                const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
-                const float lv = valid[j] ? rowlive : 0.f;         // surplus lanes / rows of a short last group add nothing
-                uint64_t tm = 0;
+                for (int j = 0; j < CH; ++j) {
+                    float w[8], G[8], x[8];
+                    cw[j].unpack(w);
+                    cg[j].unpack(G);
+                    float gsc = 0.f, armc = 0.f;
+                    float cmx = -INFINITY, cmn = INFINITY;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float v = w[i] * cm[j][i];
-                    const float a2 = v;
-                    if (has_rd) v = div_nr(v, rd, inv_rd);
-                    if (has_rm) v = v * rm;
-                    const float tq = v * inv_s;
-                    const float u = (regular ? rintf(tq) : rne_ste(tq)) + z;
-                    const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
-                    const bool in = ident || qv == u;
-                    const float Gr = G[i] * lv;
-                    gs = fmaf(Gr, (qv - z) - (in ? tq : 0.f), gs);
-                    const uint64_t mh = __builtin_amdgcn_fcmpf(v, hi, 1) & vmask;      // FCMP_OEQ
-                    const uint64_t ml = __builtin_amdgcn_fcmpf(v, lo, 1) & vmask;
-                    whi += __builtin_popcountll(mh);
-                    wlo += __builtin_popcountll(ml);
-                    tm |= mh | ml;
-                    const float gi = in ? Gr : 0.f;
-                    if (need_row) arm = fmaf(gi, a2 * inv_rd, arm);
-                    if (need_cm) acc_cm[j][i] = fmaf(gi * rmrd, w[i], acc_cm[j][i]);
-                    if (need_sh) acc_sh[j][i] = fmaf(gws * (valid[j] ? 1.f : 0.f), w[i], acc_sh[j][i]);
+                    for (int i = 0; i < 8; ++i) {
+                        const float a2 = w[i] * cm[j][i];
+                        float v = a2;
+                        if (has_rd) v = div_nr(v, rd, inv_rd);
+                        if (has_rm) v = v * rm;
+                        x[i] = v;
+                        cmx = __builtin_fmaxf(cmx, v);
+                        cmn = __builtin_fminf(cmn, v);
+                        const float tq = v * inv_s;
+                        const float u = rintf(tq) + zr;
+                        const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
+                        const bool in = ident || qv == u;
+                        const float gi = in ? G[i] : 0.f;
+                        gsc = fmaf(G[i], qv - z, gsc);
+                        gsc = fmaf(-gi, tq, gsc);
+                        // accumulated unconditionally (a uniform `if` around an fma becomes a per-element select);
+                        // what is not asked for is not stored
+                        if (MODE != 0) armc = fmaf(gi, MODE == 1 ? v : (MODE == 2 ? a2 : a2 * inv_rd), armc);
+                        acc_cm[j][i] = fmaf(MODE == 0 ? gi : gi * rmrd, w[i], acc_cm[j][i]);
+                        acc_sh[j][i] = fmaf(gws, w[i], acc_sh[j][i]);
+                    }
+                    // surplus lanes re-read the row's last chunk: their column accumulators are never stored, their row
+                    // sums and ties are dropped here
+                    gs += valid[j] ? gsc : 0.f;
+                    arm += valid[j] ? armc : 0.f;
+                    const uint64_t hit = __builtin_amdgcn_ballot_w64(valid[j] && (cmx == hi || cmn == lo));
+                    if (hit != 0) {          // this wave holds an amax / amin element of the row in this chunk (rare)
+                        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            whi += __builtin_popcountll(__builtin_amdgcn_fcmpf(x[i], hi, 1) & vmask);      // FCMP_OEQ
+                            wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(x[i], lo, 1) & vmask);
+                        }
+                        tieflag |= 1u << (rr * CH + j);
+                    }
                 }
-                if (tm != 0) tieflag |= 1u << (rr * CH + j);
+                if (ident) gs = 0.f;
             }
             gs = wave_sum(gs);
             arm = wave_sum(arm);
             if (lane == 0) *reinterpret_cast<f32x4*>(&part[wid][rr][0]) = f32x4{gs, (float)whi, (float)wlo, arm};
-            if (rr + 1 < RG) {
 #pragma unroll
-                for (int j = 0; j < CH; ++j) { cw[j] = nw_[j]; cg[j] = ng_[j]; }
-            }
+            for (int j = 0; j < CH; ++j) { cw[j] = n1w[j]; cg[j] = n1g[j]; n1w[j] = nw_[j]; n1g[j] = ng_[j]; }
         }
         __syncthreads();
         // ---- phase C: wave w finalises row w --------------------------------------------------------------------------
@@ -743,7 +769,6 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
                 const f32x4 q4 = *reinterpret_cast<const f32x4*>(&part[w2][wid][0]);
                 gs += q4[0]; nhi += q4[1]; nlo += q4[2]; arm += q4[3];
             }
-            if (ident) gs = 0.f;
             float ds_dhs, ds_dls;
             if (p.symmetric) {
                 const float lvl = (float)((1 << (p.nbits - 1)) - 1);
@@ -757,8 +782,8 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
                 ds_dhs = pass * wa * sh_ / lvl;
                 ds_dls = pass * (1.f - wa) * sg / lvl;
             } else {
-                ds_dhs = 1.f / Q;
-                ds_dls = -1.f / Q;
+                ds_dhs = p.inv_q;
+                ds_dls = -p.inv_q;
             }
             const float g_hs = gs * ds_dhs, g_ls = gs * ds_dls;
             if (r0 + wid < p.rows) {
@@ -786,7 +811,7 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
                         const f32x4 qc = *reinterpret_cast<const f32x4*>(&qps[rr][8]);
                         const f32x4 tt4 = *reinterpret_cast<const f32x4*>(&ties[rr][0]);
                         const float hi = qb[0], lo = qb[1], rd = qb[2], rm = qb[3], inv_rd = qc[0], rmrd = qc[1];
-                        const float lv = valid[j] ? qc[3] : 0.f;
+                        const float lv = valid[j] ? 1.f : 0.f;
                         float w[8];
                         Vec8<TIN>::load(wbase + row_of(rr) * K + cc[j], w);      // rare: reloaded (cache hit), not kept
 #pragma unroll
@@ -874,10 +899,19 @@ static int letq_ch(int64_t cols) {
         if (ch == 2) hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 2>), grid, dim3(256), 0, st, p);         \
         else hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 3>), grid, dim3(256), 0, st, p);                 \
     } while (0)
+#define LQ_BWD_M(TIN, TG, M)                                                                                 \
+    do {                                                                                                     \
+        if (ch == 2) hipLaunchKernelGGL((letq_bwd_kernel<TIN, TG, 2, M>), grid, dim3(256), 0, st, p);        \
+        else hipLaunchKernelGGL((letq_bwd_kernel<TIN, TG, 3, M>), grid, dim3(256), 0, st, p);                \
+    } while (0)
 #define LQ_BWD(TIN, TG)                                                                                      \
     do {                                                                                                     \
-        if (ch == 2) hipLaunchKernelGGL((letq_bwd_kernel<TIN, TG, 2>), grid, dim3(256), 0, st, p);           \
-        else hipLaunchKernelGGL((letq_bwd_kernel<TIN, TG, 3>), grid, dim3(256), 0, st, p);                   \
+        switch ((p.row_div ? 1 : 0) | (p.row_mul ? 2 : 0)) {                                                 \
+            case 0: LQ_BWD_M(TIN, TG, 0); break;                                                             \
+            case 1: LQ_BWD_M(TIN, TG, 1); break;                                                             \
+            case 2: LQ_BWD_M(TIN, TG, 2); break;                                                             \
+            default: LQ_BWD_M(TIN, TG, 3); break;                                                            \
+        }                                                                                                    \
     } while (0)
 
 static int letq_fwd(const FQ& p, int ch, int w_dtype, int y_dtype, void* stream) {
