@@ -191,6 +191,16 @@ __device__ __forceinline__ float vmin(float a, float b) {
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 
 static inline int oq_dtype_size(int dt) { return dt == OQ_F32 ? 4 : 2; }
 static inline bool oq_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -970,7 +970,7 @@ extern "C" int64_t oq_fakequant_bwd_workspace(int64_t rows, int64_t cols) {
     int64_t grid = rows < cap ? rows : cap;
     const int64_t rq = oq_rowq_bwd_blocks(rows, cols);      // the wave-per-row kernels write one partial row per workgroup
     if (rq > grid) grid = rq;
-    const int64_t lq = dbg_env("OQ_LETQ_BWD_BLOCKS", 512);   // row-group LET kernels: one partial row per workgroup
+    const int64_t lq = oq_letq_bwd_blocks(rows);            // row-group LET kernels: one partial row per workgroup
     if (lq > grid) grid = lq;
     return 2 * grid * cols;
 }

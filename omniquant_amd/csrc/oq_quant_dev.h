@@ -219,4 +219,5 @@ int n_cus() {
 int oq_rowq_fwd(const FQ& p, int w_dtype, int y_dtype, void* stream);
 int oq_rowq_bwd(const FQ& p, int w_dtype, int g_dtype, float* workspace, int64_t workspace_floats, int64_t* partial_rows,
                 void* stream);
+int64_t oq_letq_bwd_blocks(int64_t rows);
 int64_t oq_rowq_bwd_blocks(int64_t rows, int64_t cols);     // workgroups that write column partials (workspace rows)

@@ -470,8 +470,10 @@ struct RowQ {       // per-row constants handed from the finalising wave to ever
     float s, z, inv_s, regular, hi, lo, rd, rm, inv_rd, rmrd, gws, live;
 };
 
-template <typename TIN, typename TOUT, int CH>
+// MODE: bit 0 = row_div present, bit 1 = row_mul present (compile-time: no per-element selects for them)
+template <typename TIN, typename TOUT, int CH, int MODE>
 __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_FWD_WPE : 2) letq_fwd_kernel(FQ p) {
+    constexpr bool has_rd = (MODE & 1) != 0, has_rm = (MODE & 2) != 0;
     __shared__ __attribute__((aligned(16))) float part[4][RG][4];
     __shared__ __attribute__((aligned(16))) float qps[RG][4];
     const int lane = threadIdx.x & 63;
@@ -495,7 +497,6 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_FWD_WPE : 2) letq_fwd_kern
     const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
     const bool lwc = p.up != nullptr;
-    const bool has_rd = p.row_div != nullptr, has_rm = p.row_mul != nullptr;
     const int64_t ngroups = (p.rows + RG - 1) / RG;
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
         const int64_t r0 = g * RG;
@@ -526,9 +527,12 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_FWD_WPE : 2) letq_fwd_kern
                     if (has_rd) v = div_nr(v, rd, inv_rd);
                     if (has_rm) v = v * rm;
                     x[rr][j][i] = v;
-                    hi = vmax(hi, v);
-                    lo = vmin(lo, v);
-                    nanm |= __builtin_amdgcn_fcmpf(v, v, 8);       // FCMP_UNO
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    hi = vmax3(hi, x[rr][j][i], x[rr][j][i + 1]);
+                    lo = vmin3(lo, x[rr][j][i], x[rr][j][i + 1]);
+                    nanm |= __builtin_amdgcn_fcmpf(x[rr][j][i], x[rr][j][i + 1], 8);      // FCMP_UNO: either one is NaN
                 }
             }
             hi = wave_max(hi);
@@ -610,6 +614,10 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
     __shared__ __attribute__((aligned(16))) float part[4][RG][4];
     __shared__ __attribute__((aligned(16))) float qps2[2][RG][12];    // by group parity: phase A of the next group overlaps phase D
     __shared__ __attribute__((aligned(16))) float ties[RG][4];
+    // 16-bit weights: a chunk that holds an amax / amin element is parked in LDS by the wave that met it (phase B) and read
+    // back by the same wave in phase D, instead of being fetched from global memory a second time
+    constexpr bool STASH = sizeof(TIN) == 2;
+    __shared__ __attribute__((aligned(16))) Raw8<TIN> stash[STASH ? 4 * RG * CH * 64 : 1];
     constexpr bool has_rd = (MODE & 1) != 0, has_rm = (MODE & 2) != 0;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -636,25 +644,38 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
     const bool lwc = p.up != nullptr;
     const int64_t ngroups = (p.rows + RG - 1) / RG;
     int par = 0;
-    // the rows a workgroup walks form one stream: while row t is processed rows t+1 and t+2 are in flight, across group
-    // boundaries too (the next group's first rows load under phases C, D and A); three rows of raw vectors live at a time
+    // the rows a workgroup walks form one stream: while row t is processed row t+1 is in flight, across group boundaries
+    // too (the next group's first row loads under phases C, D and A); two rows of raw vectors live at a time.  (Deeper
+    // register rings were measured: copies between ring slots wait for the load they move, and four statically
+    // assigned slots cost 30 VGPRs and ran 15 % slower.)
     auto stream_row = [&](int64_t g, int k) -> int64_t {
         const int64_t r = k < RG ? g * RG + k : (g + gridDim.x) * RG + (k - RG);
         return r < p.rows ? r : p.rows - 1;        // past the end: a re-read of the last row nobody uses
     };
-    Raw8<TIN> cw[CH], n1w[CH];
-    Raw8<TG> cg[CH], n1g[CH];
+    // the same for the per-row constants phase A needs: those of the workgroup's next group are fetched one group ahead
+    struct RowIn { float hi, lo, rd, rm, gws, up, low; };
+    auto fetch_row_in = [&](int64_t g) -> RowIn {
+        int64_t r = g * RG + wid;
+        r = r < p.rows ? r : p.rows - 1;
+        RowIn o;
+        o.hi = p.xmax[r]; o.lo = p.xmin[r];
+        o.rd = has_rd ? p.row_div[r] : 1.f;
+        o.rm = has_rm ? p.row_mul[r] : 1.f;
+        o.gws = p.g_wshift ? p.g_wshift[r] : 0.f;
+        o.up = lwc ? p.up[r] : 0.f;
+        o.low = lwc ? p.low[r] : 0.f;
+        return o;
+    };
+    Raw8<TIN> cw[CH];
+    Raw8<TG> cg[CH];
+    RowIn nxt{};
     if ((int64_t)blockIdx.x < ngroups) {
-        const int64_t ra = stream_row(blockIdx.x, 0), rb = stream_row(blockIdx.x, 1);
+        nxt = fetch_row_in(blockIdx.x);
+        const int64_t ra = stream_row(blockIdx.x, 0);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             cw[j].load(wbase + ra * K + cc[j]);
             cg[j].load(gbase + ra * K + cc[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            n1w[j].load(wbase + rb * K + cc[j]);
-            n1g[j].load(gbase + rb * K + cc[j]);
         }
     }
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x, par ^= 1) {
@@ -665,14 +686,12 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
         QP q;                       // kept by the finalising wave for phase C
         float my_rm = 1.f, my_rmrd = 1.f;
         {
-            const int64_t r = row_of(wid);
-            const float hi = p.xmax[r], lo = p.xmin[r];
-            const float rd = has_rd ? p.row_div[r] : 1.f;
-            const float rm = has_rm ? p.row_mul[r] : 1.f;
-            const float gws = p.g_wshift ? p.g_wshift[r] : 0.f;
+            const RowIn in = nxt;
+            nxt = fetch_row_in(g + gridDim.x);      // lands under phases B .. D
+            const float hi = in.hi, lo = in.lo, rd = in.rd, rm = in.rm, gws = in.gws;
             const float inv_rd = 1.f / rd;
             float inv_s = 0.f;
-            q = make_qp(hi, lo, lwc, lwc ? p.up[r] : 0.f, lwc ? p.low[r] : 0.f, p.nbits, p.symmetric, p.inv_q, &inv_s);
+            q = make_qp(hi, lo, lwc, in.up, in.low, p.nbits, p.symmetric, p.inv_q, &inv_s);
             // scale == 0 (quirk Q1): the reference's round_ste turns x / 0 = +-inf into NaN; a NaN zero-point inside
             // round(t) + z gives the same all-NaN row without a per-element select ((r - t) + t == r for every finite t)
             const float zr = q.s == 0.f ? NAN : q.z;
@@ -693,7 +712,7 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
             Raw8<TIN> nw_[CH];
             Raw8<TG> ng_[CH];
             {
-                const int64_t rn = stream_row(g, rr + 2);
+                const int64_t rn = stream_row(g, rr + 1);
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     nw_[j].load(wbase + rn * K + cc[j]);
@@ -750,6 +769,7 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
                             wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(x[i], lo, 1) & vmask);
                         }
                         tieflag |= 1u << (rr * CH + j);
+                        if (STASH) stash[((wid * RG + rr) * CH + j) * 64 + lane] = cw[j];
                     }
                 }
                 if (ident) gs = 0.f;
@@ -758,7 +778,7 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
             arm = wave_sum(arm);
             if (lane == 0) *reinterpret_cast<f32x4*>(&part[wid][rr][0]) = f32x4{gs, (float)whi, (float)wlo, arm};
 #pragma unroll
-            for (int j = 0; j < CH; ++j) { cw[j] = n1w[j]; cg[j] = n1g[j]; n1w[j] = nw_[j]; n1g[j] = ng_[j]; }
+            for (int j = 0; j < CH; ++j) { cw[j] = nw_[j]; cg[j] = ng_[j]; }
         }
         __syncthreads();
         // ---- phase C: wave w finalises row w --------------------------------------------------------------------------
@@ -813,7 +833,8 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
                         const float hi = qb[0], lo = qb[1], rd = qb[2], rm = qb[3], inv_rd = qc[0], rmrd = qc[1];
                         const float lv = valid[j] ? 1.f : 0.f;
                         float w[8];
-                        Vec8<TIN>::load(wbase + row_of(rr) * K + cc[j], w);      // rare: reloaded (cache hit), not kept
+                        if (STASH) stash[((wid * RG + rr) * CH + j) * 64 + lane].unpack(w);
+                        else Vec8<TIN>::load(wbase + row_of(rr) * K + cc[j], w);      // 32-bit weights: reloaded (cache hit)
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             float v = w[i] * cm[j][i];
@@ -894,10 +915,19 @@ static int letq_ch(int64_t cols) {
     return 0;
 }
 
+#define LQ_FWD_M(TIN, TOUT, M)                                                                               \
+    do {                                                                                                     \
+        if (ch == 2) hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 2, M>), grid, dim3(256), 0, st, p);      \
+        else hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 3, M>), grid, dim3(256), 0, st, p);              \
+    } while (0)
 #define LQ_FWD(TIN, TOUT)                                                                                    \
     do {                                                                                                     \
-        if (ch == 2) hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 2>), grid, dim3(256), 0, st, p);         \
-        else hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 3>), grid, dim3(256), 0, st, p);                 \
+        switch ((p.row_div ? 1 : 0) | (p.row_mul ? 2 : 0)) {                                                 \
+            case 0: LQ_FWD_M(TIN, TOUT, 0); break;                                                           \
+            case 1: LQ_FWD_M(TIN, TOUT, 1); break;                                                           \
+            case 2: LQ_FWD_M(TIN, TOUT, 2); break;                                                           \
+            default: LQ_FWD_M(TIN, TOUT, 3); break;                                                          \
+        }                                                                                                    \
     } while (0)
 #define LQ_BWD_M(TIN, TG, M)                                                                                 \
     do {                                                                                                     \
@@ -988,6 +1018,14 @@ static int64_t bwd_grid(const FQ& p, const RowGeo& g, bool let) {
     return need < cap ? need : cap;
 }
 
+int64_t oq_letq_bwd_blocks(int64_t rows) {
+    // workgroups of the row-group LET backward = partial rows colreduce_kernel sums afterwards.  2 workgroups per CU, 3 when
+    // there are enough row groups to keep them balanced (11008 x 4096: 59.8 -> 56.0 us; 4096 x 4096: 32.6 vs 33.0 us)
+    const int64_t ngroups = (rows + RG - 1) / RG;
+    const int64_t cap = env_i("OQ_LETQ_BWD_BLOCKS", ngroups >= 2048 ? 768 : 512);
+    return ngroups < cap ? ngroups : cap;
+}
+
 int64_t oq_rowq_bwd_blocks(int64_t rows, int64_t cols) {
     // upper bound on the workgroups of a LET backward with column gradients (the workspace has 2 rows per workgroup)
     FQ p{};
@@ -1008,9 +1046,7 @@ int oq_rowq_bwd(const FQ& pin, int w_dtype, int g_dtype, float* workspace, int64
     if (let && !p.gx) {
         const int ch = letq_ch(p.cols);
         if (ch) {
-            const int64_t ngroups = (p.rows + RG - 1) / RG;
-            const int64_t cap = env_i("OQ_LETQ_BWD_BLOCKS", 512);
-            const int64_t nblk = ngroups < cap ? ngroups : cap;
+            const int64_t nblk = oq_letq_bwd_blocks(p.rows);
             if (p.g_col_mul || p.g_shift) {
                 OQ_CHECK_ARG(workspace && workspace_floats >= 2 * nblk * p.cols,
                              "oq_fakequant_bwd: workspace of %lld floats needed (oq_fakequant_bwd_workspace)", (long long)(2 * nblk * p.cols));
