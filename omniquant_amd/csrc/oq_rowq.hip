@@ -267,7 +267,6 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
         float hi = 0.f, lo = 0.f, inv_s = 0.f, rd = 1.f, rm = 1.f, gws = 0.f, inv_rd = 1.f, rmrd = 1.f;
         QP q;
         q.s = 1.f; q.z = 0.f; q.su = q.sl = 1.f; q.hi = q.lo = 0.f;
-        bool regular = true;
         if (livew) {
             Raw8<TIN> rw[CH];
             Raw8<TIN> ru[PRO ? CH : 1];
@@ -287,12 +286,14 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
             inv_rd = 1.f / rd;
             rmrd = rm * inv_rd;
             q = make_qp(hi, lo, lwc, lwc ? p.up[r] : 0.f, lwc ? p.low[r] : 0.f, p.nbits, p.symmetric, p.inv_q, &inv_s);
-            regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f;
             const float z = q.z;
+            // scale == 0 (quirk Q1): round_ste turns x / 0 = +-inf into NaN; a NaN zero-point inside round(t) + z gives the
+            // same all-NaN row without a per-element select ((r - t) + t == r for every finite t)
+            const float zr = q.s == 0.f ? NAN : z;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 if (j < chn) {
-                    float w[8], G[8], gin[8], uu[8], xs[8];
+                    float w[8], G[8], gin[8], uu[8], xs[8], xv[8];
                     rw[j].unpack(w);
                     rg[j].unpack(G);
 #pragma unroll
@@ -302,11 +303,10 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) { float sg; xs[i] = silu_f(w[i], &sg) * uu[i]; }
                     }
-                    const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
                     const float lv = valid[j] ? 1.f : 0.f;
                     float cm[8], ccm[8], csh[8];
                     if constexpr (LET) Vec8<float>::load(cm_s + cc[j], cm);
-                    uint64_t tm = 0;
+                    float gsc = 0.f, armc = 0.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         float v = xs[i], a2 = xs[i];
@@ -316,30 +316,45 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
                             if (p.row_div) v = div_nr(v, rd, inv_rd);
                             if (p.row_mul) v = v * rm;
                         }
+                        xv[i] = v;
                         const float tq = v * inv_s;
-                        const float u = (regular ? rintf(tq) : rne_ste(tq)) + z;
+                        const float u = rintf(tq) + zr;
                         const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
                         const bool in = ident || qv == u;                       // inside [0, Q] (false for NaN)
-                        const float Gr = G[i] * lv;                             // surplus lanes contribute nothing
-                        gs = fmaf(Gr, (qv - z) - (in ? tq : 0.f), gs);
-                        const uint64_t mh = __builtin_amdgcn_fcmpf(v, hi, 1) & vmask;      // FCMP_OEQ
-                        const uint64_t ml = __builtin_amdgcn_fcmpf(v, lo, 1) & vmask;
-                        whi += __builtin_popcountll(mh);
-                        wlo += __builtin_popcountll(ml);
-                        tm |= mh | ml;
                         gin[i] = in ? G[i] : 0.f;
+                        gsc = fmaf(G[i], qv - z, gsc);
+                        gsc = fmaf(-gin[i], tq, gsc);
                         if constexpr (LET) {
-                            const float gi = in ? Gr : 0.f;
-                            if (need_row) arm = fmaf(gi, a2 * inv_rd, arm);     // b = (w*cm)/rd, x = b*rm
+                            const float gi = gin[i] * lv;                       // surplus lanes contribute nothing
+                            if (need_row) armc = fmaf(gi, a2 * inv_rd, armc);   // b = (w*cm)/rd, x = b*rm
                             ccm[i] = (gi * rmrd) * w[i];
                             csh[i] = (gws * lv) * w[i];
                         }
+                    }
+                    gs += valid[j] ? gsc : 0.f;                                 // surplus lanes re-read the last chunk
+                    arm += valid[j] ? armc : 0.f;
+                    float cmx = xv[0], cmn = xv[0];
+#pragma unroll
+                    for (int i = 1; i < 7; i += 2) {
+                        cmx = vmax3(cmx, xv[i], xv[i + 1]);
+                        cmn = vmin3(cmn, xv[i], xv[i + 1]);
+                    }
+                    cmx = vmax(cmx, xv[7]);
+                    cmn = vmin(cmn, xv[7]);
+                    const uint64_t hit = __builtin_amdgcn_ballot_w64(valid[j] && (cmx == hi || cmn == lo));
+                    if (hit != 0) {          // this wave holds an amax / amin element of the row in this chunk (rare)
+                        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            whi += __builtin_popcountll(__builtin_amdgcn_fcmpf(xv[i], hi, 1) & vmask);      // FCMP_OEQ
+                            wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(xv[i], lo, 1) & vmask);
+                        }
+                        tieflag |= 1u << j;
                     }
                     if constexpr (LET) {
                         if (need_cm) slab_add(acc_cm, acc_stride / 2, j * 64 + lane, ccm);
                         if (need_sh) slab_add(acc_sh, acc_stride / 2, j * 64 + lane, csh);
                     }
-                    if (tm != 0) tieflag |= 1u << j;
                     if (p.gx) store_grads(r * K + cc[j], gin, w, uu);          // tie chunks are rewritten below
                 }
             }
@@ -409,7 +424,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
                             if (p.row_mul) v = v * rm;
                         }
                         const float tq = v * inv_s;
-                        const float u = (regular ? rintf(tq) : rne_ste(tq)) + z;
+                        const float u = rintf(tq) + (q.s == 0.f ? NAN : z);
                         const bool in = __builtin_amdgcn_fmed3f(u, 0.f, Q) == u;
                         float tt = 0.f;
                         if (v == hi) tt += tie_hi;
