@@ -221,7 +221,7 @@ struct NQ {
     int want_b;
 };
 
-template <typename TIN, typename TOUT, int CH>
+template <typename TIN, typename TOUT, int CH, bool LN>
 __global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
@@ -261,22 +261,25 @@ __global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
         for (int j = 0; j < CH; ++j)
             if (j < chn) {
                 Vec8<TIN>::load(xbase + r * K + cc[j], v[j]);
-                const float lv = valid[j] ? 1.f : 0.f;
+                float sc = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) s += lv * (p.ln ? v[j][i] : v[j][i] * v[j][i]);
+                for (int i = 0; i < 8; ++i) sc = LN ? sc + v[j][i] : fmaf(v[j][i], v[j][i], sc);
+                s += valid[j] ? sc : 0.f;       // surplus lanes hold a copy of the row's last chunk
             }
         const int op0[4] = {0, 0, 0, 0};
         float e4[4] = {wave_sum(s), 0.f, 0.f, 0.f};
         if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, e4, op0);
         float mean = 0.f, var;
-        if (p.ln) {
+        if (LN) {
             mean = e4[0] * invK;
             float s2 = 0.f;
 #pragma unroll
             for (int j = 0; j < CH; ++j)
-                if (j < chn && valid[j]) {
+                if (j < chn) {
+                    float sc = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { const float d = v[j][i] - mean; s2 += d * d; }
+                    for (int i = 0; i < 8; ++i) { const float d = v[j][i] - mean; sc = fmaf(d, d, sc); }
+                    s2 += valid[j] ? sc : 0.f;
                 }
             float f4[4] = {wave_sum(s2), 0.f, 0.f, 0.f};
             if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, f4, op0);
@@ -295,12 +298,14 @@ __global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
                 Vec8<float>::load(b_s + cc[j], bv);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float xh = (v[j][i] - mean) * rstd;
-                    const float h = wv[i] * xh + bv[i];
-                    v[j][i] = h;
-                    hi = vmax(hi, h);
-                    lo = vmin(lo, h);
-                    nanm |= __builtin_amdgcn_fcmpf(h, h, 8);
+                    const float xh = LN ? (v[j][i] - mean) * rstd : v[j][i] * rstd;
+                    v[j][i] = wv[i] * xh + bv[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    hi = vmax3(hi, v[j][i], v[j][i + 1]);
+                    lo = vmin3(lo, v[j][i], v[j][i + 1]);
+                    nanm |= __builtin_amdgcn_fcmpf(v[j][i], v[j][i + 1], 8);       // FCMP_UNO: either one is NaN
                 }
             }
         float m4[4] = {wave_max(hi), wave_min(lo), nanm != 0 ? 1.f : 0.f, 0.f};
@@ -346,8 +351,8 @@ __global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
     }
 }
 
-template <typename TIN, typename TG, int CH>
-__global__ void __launch_bounds__(512) normq_bwd_kernel(NQ p, int nw, int chn) {
+template <typename TIN, typename TG, int CH, bool LN>
+__global__ void __launch_bounds__(512, CH <= 2 ? 2 : 1) normq_bwd_kernel(NQ p, int nw, int chn) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -368,7 +373,7 @@ __global__ void __launch_bounds__(512) normq_bwd_kernel(NQ p, int nw, int chn) {
     __syncthreads();
     bool valid[CH];
     int cc[CH];
-    float aw[CH][8], ab[CH][8];
+    float aw[CH][8], ab[CH][8];          // column accumulators; those of surplus lanes are never stored
 #pragma unroll
     for (int j = 0; j < CH; ++j) {
         const int c = (j * nw + wsub) * 64 + lane;
@@ -386,61 +391,81 @@ __global__ void __launch_bounds__(512) normq_bwd_kernel(NQ p, int nw, int chn) {
     const float invK = 1.f / (float)K;
     int par = 0;
     for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
-        const bool livew = r0 + rslot < p.rows;
+        const bool livew = r0 + rslot < p.rows;     // wave-uniform; the waves of a row past the end only keep the barriers company
         const int64_t r = livew ? r0 + rslot : p.rows - 1;
-        const float live = livew ? 1.f : 0.f;
         const float rstd = p.rstd[r];
-        const float mean = (p.ln && p.mean) ? p.mean[r] : 0.f;
+        const float mean = (LN && p.mean) ? p.mean[r] : 0.f;
         const float hi = p.xmax[r], lo = p.xmin[r];
         float inv_s = 0.f;
         const QP q = make_qp(hi, lo, false, 0.f, 0.f, p.nbits, 0, p.inv_q, &inv_s);
-        const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f;
+        // scale == 0 (quirk Q1): round_ste turns h / 0 = +-inf into NaN; a NaN zero-point inside round(t) + z gives the same
+        // all-NaN row without a per-element select ((r - t) + t == r for every finite t)
+        const float zr = q.s == 0.f ? NAN : q.z;
         float xh[CH][8], gh[CH][8];
         float gs = 0.f;
         int whi = 0, wlo = 0;
         uint32_t tieflag = 0;
+        Raw8<TG> ga[CH];                 // the addend of the result (residual branch) is fetched with the row, not after it
+        if (livew && abase) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j)
-            if (j < chn) {
-                float G[8], wv[8], bv[8];
-                Vec8<TIN>::load(xbase + r * K + cc[j], xh[j]);
-                Vec8<TG>::load(gbase + r * K + cc[j], G);
-                if (g2base) {       // dL/dy arrives in pieces (one per consumer of y): added here, in a fixed order
-                    float G2[8];
-                    Vec8<TG>::load(g2base + r * K + cc[j], G2);
+            for (int j = 0; j < CH; ++j)
+                if (j < chn) ga[j].load(abase + r * K + cc[j]);
+        }
+        if (livew) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) G[i] += G2[i];
+            for (int j = 0; j < CH; ++j)
+                if (j < chn) {
+                    float G[8], wv[8], bv[8], hv[8];
+                    Vec8<TIN>::load(xbase + r * K + cc[j], xh[j]);
+                    Vec8<TG>::load(gbase + r * K + cc[j], G);
+                    if (g2base) {       // dL/dy arrives in pieces (one per consumer of y): added here, in a fixed order
+                        float G2[8];
+                        Vec8<TG>::load(g2base + r * K + cc[j], G2);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) G[i] += G2[i];
+                    }
+                    if (g3base) {
+                        float G3[8];
+                        Vec8<TG>::load(g3base + r * K + cc[j], G3);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) G[i] += G3[i];
+                    }
+                    Vec8<float>::load(w_s + cc[j], wv);
+                    Vec8<float>::load(b_s + cc[j], bv);
+                    float gsc = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        xh[j][i] = LN ? (xh[j][i] - mean) * rstd : xh[j][i] * rstd;
+                        const float h = wv[i] * xh[j][i] + bv[i];
+                        hv[i] = h;
+                        const float tq = h * inv_s;
+                        const float u = rintf(tq) + zr;
+                        const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
+                        gh[j][i] = qv == u ? G[i] : 0.f;
+                        gsc = fmaf(G[i], qv - q.z, gsc);
+                        gsc = fmaf(-gh[j][i], tq, gsc);
+                    }
+                    gs += valid[j] ? gsc : 0.f;         // surplus lanes hold a copy of the row's last chunk
+                    float cmx = hv[0], cmn = hv[0];
+#pragma unroll
+                    for (int i = 1; i < 7; i += 2) {
+                        cmx = vmax3(cmx, hv[i], hv[i + 1]);
+                        cmn = vmin3(cmn, hv[i], hv[i + 1]);
+                    }
+                    cmx = vmax(cmx, hv[7]);
+                    cmn = vmin(cmn, hv[7]);
+                    const uint64_t hit = __builtin_amdgcn_ballot_w64(valid[j] && (cmx == hi || cmn == lo));
+                    if (hit != 0) {      // this wave holds an amax / amin element of the row in this chunk (rare)
+                        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            whi += __builtin_popcountll(__builtin_amdgcn_fcmpf(hv[i], hi, 1) & vmask);      // FCMP_OEQ
+                            wlo += __builtin_popcountll(__builtin_amdgcn_fcmpf(hv[i], lo, 1) & vmask);
+                        }
+                        tieflag |= 1u << j;
+                    }
                 }
-                if (g3base) {
-                    float G3[8];
-                    Vec8<TG>::load(g3base + r * K + cc[j], G3);
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) G[i] += G3[i];
-                }
-                Vec8<float>::load(w_s + cc[j], wv);
-                Vec8<float>::load(b_s + cc[j], bv);
-                const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid[j]);
-                const float lv = valid[j] ? live : 0.f;
-                uint64_t tm = 0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    xh[j][i] = (xh[j][i] - mean) * rstd;
-                    const float h = wv[i] * xh[j][i] + bv[i];
-                    const float tq = h * inv_s;
-                    const float u = (regular ? rintf(tq) : rne_ste(tq)) + q.z;
-                    const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
-                    const bool in = qv == u;
-                    const float Gr = G[i] * lv;
-                    gs = fmaf(Gr, (qv - q.z) - (in ? tq : 0.f), gs);
-                    const uint64_t mh = __builtin_amdgcn_fcmpf(h, hi, 1) & vmask;
-                    const uint64_t ml = __builtin_amdgcn_fcmpf(h, lo, 1) & vmask;
-                    whi += __builtin_popcountll(mh);
-                    wlo += __builtin_popcountll(ml);
-                    tm |= mh | ml;
-                    gh[j][i] = in ? Gr : 0.f;
-                }
-                if (tm != 0) tieflag |= 1u << j;
-            }
+        }
         const int op0[4] = {0, 0, 0, 0};
         float e4[4] = {wave_sum(gs), (float)whi, (float)wlo, 0.f};
         if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, e4, op0);
@@ -452,46 +477,50 @@ __global__ void __launch_bounds__(512) normq_bwd_kernel(NQ p, int nw, int chn) {
                     float wv[8], bv[8];
                     Vec8<float>::load(w_s + cc[j], wv);
                     Vec8<float>::load(b_s + cc[j], bv);
-                    const float lv = valid[j] ? live : 0.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float h = wv[i] * xh[j][i] + bv[i];
-                        if (h == hi) gh[j][i] += tie_hi * lv;
-                        if (h == lo) gh[j][i] += tie_lo * lv;
+                        if (h == hi) gh[j][i] += tie_hi;
+                        if (h == lo) gh[j][i] += tie_lo;
                     }
                 }
         }
         // ---- norm backward on dL/dh = gh ----
         float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < CH; ++j)
-            if (j < chn) {
-                float wv[8];
-                Vec8<float>::load(w_s + cc[j], wv);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    aw[j][i] += gh[j][i] * xh[j][i];
-                    ab[j][i] += gh[j][i];
-                    gh[j][i] = gh[j][i] * wv[i];
-                    s1 += gh[j][i];
-                    s2 += gh[j][i] * xh[j][i];
-                }
-            }
-        float f4[4] = {wave_sum(s1), wave_sum(s2), 0.f, 0.f};
-        if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, f4, op0);
-        const float m1 = p.ln ? f4[0] * invK : 0.f, m2 = f4[1] * invK;
         if (livew) {
 #pragma unroll
             for (int j = 0; j < CH; ++j)
-                if (j < chn && valid[j]) {      // surplus lanes hold a masked copy of the last chunk: they must not store
+                if (j < chn) {
+                    float wv[8];
+                    Vec8<float>::load(w_s + cc[j], wv);
+                    float s1c = 0.f, s2c = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        aw[j][i] = fmaf(gh[j][i], xh[j][i], aw[j][i]);
+                        ab[j][i] += gh[j][i];
+                        gh[j][i] = gh[j][i] * wv[i];
+                        s1c += gh[j][i];
+                        s2c = fmaf(gh[j][i], xh[j][i], s2c);
+                    }
+                    s1 += valid[j] ? s1c : 0.f;
+                    s2 += valid[j] ? s2c : 0.f;
+                }
+        }
+        float f4[4] = {wave_sum(s1), wave_sum(s2), 0.f, 0.f};
+        if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, f4, op0);
+        const float m1 = LN ? f4[0] * invK : 0.f, m2 = f4[1] * invK;
+        if (livew) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+                if (j < chn && valid[j]) {      // surplus lanes hold a copy of the last chunk: they must not store
                     float o[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) o[i] = (gh[j][i] - m1 - xh[j][i] * m2) * rstd;
+                    for (int i = 0; i < 8; ++i) o[i] = LN ? (gh[j][i] - m1 - xh[j][i] * m2) * rstd : (gh[j][i] - xh[j][i] * m2) * rstd;
                     if (abase) {
-                        float ga[8];
-                        Vec8<TG>::load(abase + r * K + cc[j], ga);
+                        float gav[8];
+                        ga[j].unpack(gav);
 #pragma unroll
-                        for (int i = 0; i < 8; ++i) o[i] += ga[i];
+                        for (int i = 0; i < 8; ++i) o[i] += gav[i];
                     }
                     Vec8<TG>::store(gxbase + r * K + cc[j], o);
                 }
@@ -606,16 +635,29 @@ extern "C" int64_t oq_norm_quant_supported(int dtype, int64_t cols) {
     return (dtype == OQ_BF16 || dtype == OQ_F32) && row_geo(cols, 0, &g) && cols <= 8192;
 }
 
+// Backward geometry.  Rows of >= 4096 elements: 4 waves per row (2 chunks per lane at 4096: 134 VGPRs instead of 208) in
+// workgroups of 8 waves, ONE workgroup per CU -- what a workgroup pays once (staging weight / bias in LDS, folding and
+// writing its partial column sums) outweighs the extra workgroups' parallelism at the 2048 rows of a calibration sample:
+// in-step 43.4 + 7.9 us (2 waves per row, 512 workgroups of 4 waves) -> 38.6 + 5.3 us per launch (tools/_nq_sweep.sh).
+static bool normq_bwd_geo(int64_t cols, RowGeo* g) {
+    const int nw_env = (int)env_i("OQ_NORMQ_BWD_NW", 0);
+    if (!row_geo(cols, nw_env > 0 ? nw_env : (cols >= 4096 ? 4 : 0), g)) return false;
+    int wpb = (int)env_i("OQ_NORMQ_BWD_WPB", 0);            // waves per workgroup (rows per workgroup = wpb / nw)
+    if (wpb == 0 && g->nw == 4) wpb = 8;
+    if (wpb >= g->nw && wpb <= 8 && wpb % g->nw == 0) g->wpb = wpb;
+    return true;
+}
+
 static int64_t normq_bwd_grid(int64_t rows, const RowGeo& g) {
     const int rpb = g.wpb / g.nw;
     const int64_t need = (rows + rpb - 1) / rpb;
-    const int64_t cap = env_i("OQ_NORMQ_BWD_BLOCKS", 512);
+    const int64_t cap = env_i("OQ_NORMQ_BWD_BLOCKS", g.wpb == 8 ? n_cus() : 512);
     return need < cap ? need : cap;
 }
 
 extern "C" int64_t oq_norm_quant_bwd_workspace(int64_t rows, int64_t cols) {
     RowGeo g;
-    if (!row_geo(cols, (int)env_i("OQ_NORMQ_BWD_NW", 0), &g)) return 0;
+    if (!normq_bwd_geo(cols, &g)) return 0;
     return 2 * normq_bwd_grid(rows, g) * cols;
 }
 
@@ -640,9 +682,10 @@ extern "C" int oq_norm_quant_fwd(const void* x, int dtype, int64_t rows, int64_t
     const dim3 grid((unsigned)(need < cap ? need : cap)), blk((unsigned)(g.wpb * 64));
     const size_t smem = sizeof(float) * (2 * cols + 64);
     hipStream_t st = (hipStream_t)stream;
-#define NQ_FWD(T_) do { if (g.chn <= 4) hipLaunchKernelGGL((normq_fwd_kernel<T_, T_, 4>), grid, blk, smem, st, p, g.nw, g.chn); \
-                        else hipLaunchKernelGGL((normq_fwd_kernel<T_, T_, 8>), grid, blk, smem, st, p, g.nw, g.chn); } while (0)
-    if (dtype == OQ_BF16) NQ_FWD(bf16_t); else NQ_FWD(float);
+#define NQ_FWD(T_, LN_) do { if (g.chn <= 4) hipLaunchKernelGGL((normq_fwd_kernel<T_, T_, 4, LN_>), grid, blk, smem, st, p, g.nw, g.chn); \
+                             else hipLaunchKernelGGL((normq_fwd_kernel<T_, T_, 8, LN_>), grid, blk, smem, st, p, g.nw, g.chn); } while (0)
+    if (dtype == OQ_BF16) { if (is_layernorm) NQ_FWD(bf16_t, true); else NQ_FWD(bf16_t, false); }
+    else { if (is_layernorm) NQ_FWD(float, true); else NQ_FWD(float, false); }
     OQ_CHECK_LAUNCH("oq_norm_quant_fwd");
     return OQ_OK;
 }
@@ -656,7 +699,7 @@ extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, const void* g2, 
                  "oq_norm_quant_bwd: 16-byte alignment");
     OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_norm_quant_bwd: rows %lld, bitwidth %d", (long long)rows, nbits);
     RowGeo g;
-    if (!oq_norm_quant_supported(dtype, cols) || !row_geo(cols, (int)env_i("OQ_NORMQ_BWD_NW", 0), &g)) {
+    if (!oq_norm_quant_supported(dtype, cols) || !normq_bwd_geo(cols, &g)) {
         oq_set_error("oq_norm_quant_bwd: dtype %d / %lld columns unsupported", dtype, (long long)cols);
         return OQ_E_UNSUPPORTED;
     }
@@ -672,17 +715,23 @@ extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, const void* g2, 
     const dim3 grid((unsigned)nblk), blk((unsigned)(g.wpb * 64));
     const size_t smem = sizeof(float) * (2 * cols + 64 + (size_t)g.wpb * g.chn * 512);
     hipStream_t st = (hipStream_t)stream;
-    if (smem > 64 * 1024) {
-        const void* k = dtype == OQ_BF16 ? (g.chn <= 4 ? (const void*)normq_bwd_kernel<bf16_t, bf16_t, 4> : (const void*)normq_bwd_kernel<bf16_t, bf16_t, 8>)
-                                         : (g.chn <= 4 ? (const void*)normq_bwd_kernel<float, float, 4> : (const void*)normq_bwd_kernel<float, float, 8>);
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
-            oq_set_error("oq_norm_quant_bwd: cannot reserve %zu bytes of LDS", smem);
+#define NQ_BWD_K(T_, C_, LN_) ((const void*)normq_bwd_kernel<T_, T_, C_, LN_>)
+#define NQ_BWD_SEL(T_) (g.chn <= 2 ? (is_layernorm ? NQ_BWD_K(T_, 2, true) : NQ_BWD_K(T_, 2, false))  \
+                      : g.chn <= 4 ? (is_layernorm ? NQ_BWD_K(T_, 4, true) : NQ_BWD_K(T_, 4, false))  \
+                                   : (is_layernorm ? NQ_BWD_K(T_, 8, true) : NQ_BWD_K(T_, 8, false)))
+    const void* k = dtype == OQ_BF16 ? NQ_BWD_SEL(bf16_t) : NQ_BWD_SEL(float);
+    if (smem > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        oq_set_error("oq_norm_quant_bwd: cannot reserve %zu bytes of LDS", smem);
+        return OQ_E_LAUNCH;
+    }
+    {
+        int nw_ = g.nw, chn_ = g.chn;
+        void* args[] = {&p, &nw_, &chn_};
+        if (hipLaunchKernel(k, grid, blk, args, smem, st) != hipSuccess) {
+            oq_set_error("oq_norm_quant_bwd: launch failed");
             return OQ_E_LAUNCH;
         }
     }
-#define NQ_BWD(T_) do { if (g.chn <= 4) hipLaunchKernelGGL((normq_bwd_kernel<T_, T_, 4>), grid, blk, smem, st, p, g.nw, g.chn); \
-                        else hipLaunchKernelGGL((normq_bwd_kernel<T_, T_, 8>), grid, blk, smem, st, p, g.nw, g.chn); } while (0)
-    if (dtype == OQ_BF16) NQ_BWD(bf16_t); else NQ_BWD(float);
     const dim3 rg((unsigned)((cols + 15) / 16), gb ? 2 : 1);
     hipLaunchKernelGGL(norm_colreduce_kernel, rg, dim3(256), 0, st, workspace, (int)nblk, cols, gw, gb);
     OQ_CHECK_LAUNCH("oq_norm_quant_bwd");
