@@ -217,6 +217,16 @@ int oq_scale(const void* a, float s, void* y, int dtype, int64_t n, void* stream
 int oq_gradnorm(const float* g, int64_t n, float* norm_out, float* workspace, void* stream);
 int oq_adamw(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_let, float lr_let, float lr_lwc,
              float beta1, float beta2, float eps, float wd, float* step_ptr, const float* norm, void* stream);
+
+/* oq_adamw_step: the whole optimiser step of quantize/omniquant.py:226-229 (loss_scaler -> grad norm, skip on
+ * non-finite, AdamW) in three launches: grad norm (two stages; the second writes norm_out[0..1] and advances step_ptr[0]
+ * when the gradients are finite), then AdamW (as oq_adamw, reading the advanced counter) which also applies truncate_number
+ * (models/transformation.py:5-20, threshold truncate_thr) to the first n_truncate parameters -- the LET scales, what the
+ * reference does at the top of the NEXT step (models/int_llama_layer.py:281-284) -- and clears g when zero_grads != 0
+ * (the optimizer.zero_grad() of quantize/omniquant.py:225, moved behind the update).  workspace: 512 floats. */
+int oq_adamw_step(float* p, float* g, float* m, float* v, int64_t n, int64_t n_let, int64_t n_truncate, float truncate_thr,
+                  int zero_grads, float lr_let, float lr_lwc, float beta1, float beta2, float eps, float wd, float* step_ptr,
+                  float* norm_out, float* workspace, void* stream);
 int oq_truncate(float* x, int64_t n, float thr, void* stream);
 /* dst[e][i] = sum_k src[e*OQ_SUM_MAX_SRC + k][i], k < nsrc[e], i < n[e], for e < entries, in one launch and in a fixed
  * order.  Gathers the partial gradients several backward kernels produce for one shared LET parameter into the

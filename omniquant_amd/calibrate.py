@@ -131,7 +131,7 @@ class StepRunner:
         g = torch.empty_like(out)
         C.call("oq_mse_fwd_bwd", C.ptr(out), C.ptr(self.t1), C.ptr(self.t2), C.dt(out), out.numel(), 1.0,
                C.fptr(self._loss_buf), C.ptr(g), C.stream())
-        self.opt.zero_grad()
+        self.opt.zero_grad(lazy=True)       # a no-op once the fused optimiser step clears the arena behind each update
         out.backward(g)
         self.opt.step()
 
@@ -148,6 +148,8 @@ class StepRunner:
                 self._step()
             for t, c in zip((opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count), snap):
                 t.copy_(c)
+            # the captured step starts from scales the fused update keeps truncated: do it once for the restored values
+            opt.truncate_scales(force=True)
             self.qlayer.clear_temp_variable()     # drop the warm-up autograd graph
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()

@@ -61,6 +61,52 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, fl
     }
 }
 
+// ---- fused step: three launches (grad-norm partials; its single-workgroup second stage, which also advances the step
+// counter; AdamW + truncate_number of the LET scales + clearing of the gradient arena) instead of the six of
+// oq_gradnorm + oq_adamw + oq_truncate + a fill.  (Finishing the reduction in the first launch through a "last
+// workgroup" ticket was measured and dropped: the agent-scope fences it needs write back and invalidate the L2 of every
+// XCD -- the step became 20 % slower.)
+__global__ void __launch_bounds__(64) gradnorm_final_step_kernel(const float* ws, int nblocks, float* out, float* step_ptr) {
+    float ss = 0.f, bad = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) { ss += ws[2 * i]; bad = fmaxf(bad, ws[2 * i + 1]); }
+    ss = wave_sum(ss);
+    bad = wave_max(bad);
+    if (threadIdx.x == 0) {
+        const bool finite = bad == 0.f && ss == ss && ss <= 3.4028234663852886e38f;
+        out[0] = sqrtf(ss);
+        out[1] = finite ? 1.f : 0.f;
+        if (finite) step_ptr[0] += 1.f;       // the AdamW launch behind this one reads the advanced counter
+    }
+}
+
+__global__ void __launch_bounds__(256) adamw_fused_kernel(float* p, float* g, float* m, float* v, int64_t n, int64_t n_let,
+                                                          int64_t n_trunc, float thr, int zero_grads, float lr_let, float lr_lwc,
+                                                          float b1, float b2, float eps, float wd, const float* step_ptr,
+                                                          const float* norm) {
+    const bool skip = norm[1] == 0.f;     // non-finite gradients: no update (GradScaler semantics), gradients still cleared
+    const float step = step_ptr[0];       // already advanced by gradnorm_final_step_kernel
+    const float bc1 = 1.f - powf(b1, step);
+    const float bc2 = 1.f - powf(b2, step);
+    const float bc2_sqrt = sqrtf(bc2);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!skip) {
+            const float lr = i < n_let ? lr_let : lr_lwc;
+            const float gi = g[i];
+            float pi = p[i];
+            pi = pi * (1.f - lr * wd);
+            float mi = m[i], vi = v[i];
+            mi = mi + (gi - mi) * (1.f - b1);                 // lerp_, as torch
+            vi = vi * b2 + (1.f - b2) * (gi * gi);
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            pi = pi - (lr / bc1) * (mi / denom);
+            // truncate_number (models/transformation.py:5-20) of the LET scales: what the NEXT step would do first
+            if (i < n_trunc && fabsf(pi) < thr) pi = pi > 0.f ? thr : (pi < 0.f ? -thr : 0.f);
+            p[i] = pi; m[i] = mi; v[i] = vi;
+        }
+        if (zero_grads) g[i] = 0.f;
+    }
+}
+
 __global__ void step_inc_kernel(float* step_ptr, const float* norm) {
     if (norm && norm[1] == 0.f) return;
     step_ptr[0] += 1.f;
@@ -98,6 +144,23 @@ extern "C" int oq_adamw(float* p, const float* g, float* m, float* v, int64_t n,
                        (const float*)step_ptr, norm);
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step_ptr, norm);
     OQ_CHECK_LAUNCH("oq_adamw");
+    return OQ_OK;
+}
+
+extern "C" int oq_adamw_step(float* p, float* g, float* m, float* v, int64_t n, int64_t n_let, int64_t n_truncate,
+                             float truncate_thr, int zero_grads, float lr_let, float lr_lwc, float beta1, float beta2, float eps,
+                             float wd, float* step_ptr, float* norm_out, float* workspace, void* stream) {
+    OQ_CHECK_ARG(p && g && m && v && step_ptr && norm_out && workspace && n > 0 && n_let >= 0 && n_let <= n &&
+                 n_truncate >= 0 && n_truncate <= n, "oq_adamw_step: bad args (workspace needs %d floats)", 2 * GN_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    int64_t nb = (n + 255) / 256;
+    const int64_t gb = nb > GN_BLOCKS ? GN_BLOCKS : nb;
+    hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(gb), dim3(256), 0, st, (const float*)g, n, workspace);
+    hipLaunchKernelGGL(gradnorm_final_step_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, (int)gb, norm_out, step_ptr);
+    nb = nb > 2048 ? 2048 : nb;
+    hipLaunchKernelGGL(adamw_fused_kernel, dim3(nb), dim3(256), 0, st, p, g, m, v, n, n_let, n_truncate, truncate_thr, zero_grads,
+                       lr_let, lr_lwc, beta1, beta2, eps, wd, (const float*)step_ptr, (const float*)norm_out);
+    OQ_CHECK_LAUNCH("oq_adamw_step");
     return OQ_OK;
 }
 

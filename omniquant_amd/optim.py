@@ -9,6 +9,7 @@ their .grad tensors.  zero_grad = one memset, grad-norm = one reduction, AdamW =
 counter and the finite-flag on the device (graph-replayable, no host sync, no loss scaling needed for bf16).
 """
 import ctypes
+import os
 
 import torch
 
@@ -103,17 +104,33 @@ class BlockOptimizer:
             qlayer.__dict__["_arena_truncate"] = self.truncate_scales     # block's truncate_number -> one launch
         self.let_lr, self.lwc_lr, self.wd = float(let_lr), float(lwc_lr), float(weight_decay)
         self.betas, self.eps = betas, float(eps)
+        # fused step (oq_adamw_step): the update also truncates the LET scales (what the next step would do first) and
+        # clears the gradient arena, so the steady-state sample-step launches neither oq_truncate nor a fill.
+        # OQ_FUSED_OPT=0 keeps the separate launches for A/B.
+        self.fused = os.environ.get("OQ_FUSED_OPT", "1") != "0"
+        self.truncate_thr = 1e-2
+        self.clear_grads_in_step = True   # False: .grad survives step() as with torch (tests that read the gradients)
+        self._grads_clean = True          # the arena is all zeros (set by the fused step, cleared by anything that may write it)
+        self._scales_truncated = False    # the scales are known to satisfy |s| >= thr (set by the fused step)
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=False, lazy=False):
+        """lazy=True (the engine's own step loop): skip the launch when the fused step has just cleared the arena."""
+        if lazy and self._grads_clean:
+            return
         self.grad.zero_()
+        self._grads_clean = True
 
-    def truncate_scales(self, thr=1e-2):
+    def truncate_scales(self, thr=1e-2, force=False):
         """truncate_number over all LET scales in one launch (they are the head of the arena)."""
-        if self.n_scale:
-            C.call("oq_truncate", C.fptr(self.flat), self.n_scale, float(thr), C.stream())
+        if not self.n_scale:
+            return
+        if self._scales_truncated and not force and float(thr) == self.truncate_thr:
+            return                        # the fused step already did it behind the last update
+        C.call("oq_truncate", C.fptr(self.flat), self.n_scale, float(thr), C.stream())
 
     def collect_grads(self):
         """Finish the backward pass: one launch sums the partial gradients of the shared learnables into the arena."""
+        self._grads_clean = False
         self.collector.flush()
 
     def grad_norm(self):
@@ -123,6 +140,16 @@ class BlockOptimizer:
 
     def step(self):
         """grad-norm + AdamW; the update is skipped on device when a gradient is non-finite."""
+        if self.fused:
+            self.collector.flush()
+            C.call("oq_adamw_step", C.fptr(self.flat), C.fptr(self.grad), C.fptr(self.exp_avg), C.fptr(self.exp_avg_sq),
+                   self.n, self.n_let, self.n_scale, self.truncate_thr, int(self.clear_grads_in_step), self.let_lr,
+                   self.lwc_lr, self.betas[0], self.betas[1], self.eps, self.wd, C.fptr(self.step_count), C.fptr(self.norm),
+                   C.fptr(self._ws), C.stream())
+            self._grads_clean = self.clear_grads_in_step
+            self._scales_truncated = True
+            return self.norm[0]
+        self._grads_clean = False
         norm = self.grad_norm()
         C.call("oq_adamw", C.fptr(self.flat), C.fptr(self.grad), C.fptr(self.exp_avg), C.fptr(self.exp_avg_sq),
                self.n, self.n_let, self.let_lr, self.lwc_lr, self.betas[0], self.betas[1], self.eps, self.wd,

@@ -110,6 +110,7 @@ def test_production_step_vs_oracle(name):
     if let:
         register_let_parameters(q, "llama", sc, sh, alpha, 0, DEV)
     opt = BlockOptimizer(q, args.let_lr, args.lwc_lr, args.wd)
+    opt.clear_grads_in_step = False     # the gradients of the step are compared below (production clears them in oq_adamw_step)
     runner = StepRunner(q, opt, mask.to(DEV), pos.to(DEV), (1, T, H), torch.bfloat16, False, True, use_graph=True)
     runner.run(x.to(DEV).to(torch.bfloat16), tgt.to(DEV).to(torch.bfloat16))
     torch.cuda.synchronize()

@@ -296,6 +296,64 @@ def test_adamw_gradnorm_truncate_vs_torch():
     assert_close(x, g5["trunc_y"], 0, 0, "truncate")
 
 
+def test_adamw_step_fused_vs_torch():
+    """oq_adamw_step = grad norm + skip-on-inf + AdamW + truncate_number of the head of the arena + gradient clearing in
+    three launches (the grad-norm's second stage also advances the step counter)."""
+    from omniquant_amd import _capi as C
+    g = torch.Generator().manual_seed(3)
+    n, n_let, n_tr = 70000, 9000, 4000          # > 256 workgroups of 256: the partial stage is capped and strided
+    p0 = torch.randn(n, generator=g) * 0.02     # many |p| < 1e-2: truncation matters
+    thr = 1e-2
+
+    def trunc(x):
+        y = x.clone()
+        small = y.abs() < thr
+        y[small] = torch.sign(y[small]) * thr
+        return y
+
+    pt_let = p0[:n_let].clone().requires_grad_(True)
+    pt_lwc = p0[n_let:].clone().requires_grad_(True)
+    opt = torch.optim.AdamW([{"params": [pt_let], "lr": 5e-3}, {"params": [pt_lwc], "lr": 1e-2}], weight_decay=0.01)
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step, norm, ws = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV), torch.zeros(512, device=DEV)
+
+    def fused(gd):
+        C.call("oq_adamw_step", C.fptr(p), C.fptr(gd), C.fptr(m), C.fptr(v), n, n_let, n_tr, thr, 1, 5e-3, 1e-2, 0.9, 0.999,
+               1e-8, 0.01, C.fptr(step), C.fptr(norm), C.fptr(ws), C.stream())
+
+    for it in range(6):
+        gr = torch.randn(n, generator=g) * (10.0 ** (it - 3))
+        pt_let.grad, pt_lwc.grad = gr[:n_let].clone(), gr[n_let:].clone()
+        opt.step()
+        with torch.no_grad():                   # the reference truncates at the top of the next step
+            pt_let[:n_tr] = trunc(pt_let[:n_tr])
+        gd = gr.to(DEV)
+        fused(gd)
+        assert abs(float(norm[0]) - float(gr.norm())) <= 1e-5 * float(gr.norm())
+        assert float(norm[1]) == 1.0 and float(step) == it + 1
+        assert float(gd.abs().max()) == 0.0, "gradient arena not cleared"
+    want = torch.cat([pt_let.detach(), pt_lwc.detach()])
+    assert_close(p, want.numpy(), 1e-5, 1e-6, "fused adamw params")
+    assert float(p[:n_tr].abs().min()) >= float(torch.tensor(thr, dtype=torch.float32))
+    # non-finite gradient: no update, no step increment, gradients still cleared
+    gd = torch.randn(n, generator=g).to(DEV)
+    gd[n - 3] = float("nan")
+    before, mb, vb = p.clone(), m.clone(), v.clone()
+    fused(gd)
+    assert float(norm[1]) == 0.0 and torch.equal(p, before) and torch.equal(m, mb) and torch.equal(v, vb) and float(step) == 6.0
+    assert float(gd.abs().max()) == 0.0
+    # bit-identical for identical input
+    g1 = torch.randn(n, generator=g).to(DEV)
+    g2 = g1.clone()
+    p_snap, m_snap, v_snap, s_snap = p.clone(), m.clone(), v.clone(), step.clone()
+    fused(g1)
+    p1 = p.clone()
+    p.copy_(p_snap); m.copy_(m_snap); v.copy_(v_snap); step.copy_(s_snap)
+    fused(g2)
+    assert torch.equal(p, p1) and float(step) == 7.0
+
+
 def test_bad_arguments_raise():
     """Error convention of the boundary: negative rc -> OQError with the library's message; CPU tensors refused."""
     from omniquant_amd import ops, OQError, _capi as C
