@@ -486,11 +486,12 @@ struct RowQ {       // per-row constants handed from the finalising wave to ever
 };
 
 // MODE: bit 0 = row_div present, bit 1 = row_mul present (compile-time: no per-element selects for them)
-template <typename TIN, typename TOUT, int CH, int MODE>
-__global__ void __launch_bounds__(256, CH <= 2 ? LETQ_FWD_WPE : 2) letq_fwd_kernel(FQ p) {
+// RGT rows per group: 4, or 2 for matrices of few row groups (half the registers per wave, twice the workgroups)
+template <typename TIN, typename TOUT, int CH, int MODE, int RGT>
+__global__ void __launch_bounds__(256, CH <= 2 ? (RGT == 2 ? 4 : LETQ_FWD_WPE) : 2) letq_fwd_kernel(FQ p) {
     constexpr bool has_rd = (MODE & 1) != 0, has_rm = (MODE & 2) != 0;
-    __shared__ __attribute__((aligned(16))) float part[4][RG][4];
-    __shared__ __attribute__((aligned(16))) float qps[RG][4];
+    __shared__ __attribute__((aligned(16))) float part[4][RGT][4];
+    __shared__ __attribute__((aligned(16))) float qps[RGT][4];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int K = (int)p.cols;
@@ -512,21 +513,21 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_FWD_WPE : 2) letq_fwd_kern
     const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
     const bool lwc = p.up != nullptr;
-    const int64_t ngroups = (p.rows + RG - 1) / RG;
+    const int64_t ngroups = (p.rows + RGT - 1) / RGT;
     for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        const int64_t r0 = g * RG;
+        const int64_t r0 = g * RGT;
         // ---- phase A: load + transform this wave's columns of the 4 rows, per-row partial min / max / NaN / w@shift ----
-        Raw8<TIN> raw[RG][CH];
-        int64_t rows_[RG];
+        Raw8<TIN> raw[RGT][CH];
+        int64_t rows_[RGT];
 #pragma unroll
-        for (int rr = 0; rr < RG; ++rr) {
+        for (int rr = 0; rr < RGT; ++rr) {
             rows_[rr] = r0 + rr < p.rows ? r0 + rr : p.rows - 1;      // a short last group redoes the last row (same values)
 #pragma unroll
             for (int j = 0; j < CH; ++j) raw[rr][j].load(wbase + rows_[rr] * K + cc[j]);
         }
-        float x[RG][CH][8];
+        float x[RGT][CH][8];
 #pragma unroll
-        for (int rr = 0; rr < RG; ++rr) {
+        for (int rr = 0; rr < RGT; ++rr) {
             const float rd = has_rd ? p.row_div[rows_[rr]] : 1.f;
             const float rm = has_rm ? p.row_mul[rows_[rr]] : 1.f;
             const float inv_rd = 1.f / rd;
@@ -557,7 +558,7 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_FWD_WPE : 2) letq_fwd_kern
         }
         __syncthreads();
         // ---- phase B: wave w finalises row w ------------------------------------------------------------------------
-        {
+        if (wid < RGT) {
             const int rr = wid;
             float hi = -INFINITY, lo = INFINITY, bad = 0.f, dot = 0.f;
 #pragma unroll
@@ -580,7 +581,7 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_FWD_WPE : 2) letq_fwd_kern
         __syncthreads();
         // ---- phase C: quantise and store ------------------------------------------------------------------------------
 #pragma unroll
-        for (int rr = 0; rr < RG; ++rr) {
+        for (int rr = 0; rr < RGT; ++rr) {
             const f32x4 q4 = *reinterpret_cast<const f32x4*>(&qps[rr][0]);
             const float qs = q4[0], qz = q4[1], inv_s = q4[2];
             const bool regular = q4[3] != 0.f;
@@ -932,8 +933,9 @@ static int letq_ch(int64_t cols) {
 
 #define LQ_FWD_M(TIN, TOUT, M)                                                                               \
     do {                                                                                                     \
-        if (ch == 2) hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 2, M>), grid, dim3(256), 0, st, p);      \
-        else hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 3, M>), grid, dim3(256), 0, st, p);              \
+        if (ch == 2 && rgt == 2) hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 2, M, 2>), grid, dim3(256), 0, st, p); \
+        else if (ch == 2) hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 2, M, 4>), grid, dim3(256), 0, st, p);        \
+        else hipLaunchKernelGGL((letq_fwd_kernel<TIN, TOUT, 3, M, 4>), grid, dim3(256), 0, st, p);           \
     } while (0)
 #define LQ_FWD(TIN, TOUT)                                                                                    \
     do {                                                                                                     \
@@ -960,7 +962,10 @@ static int letq_ch(int64_t cols) {
     } while (0)
 
 static int letq_fwd(const FQ& p, int ch, int w_dtype, int y_dtype, void* stream) {
-    const int64_t ngroups = (p.rows + RG - 1) / RG;
+    // rows per group: 2 for rows <= 4096 elements (109 VGPRs, 4 workgroups per CU, twice the groups: [4096,4096] 19.3 -> 17.2 us,
+    // [11008,4096] 37.7 -> 34.6 us = 5.2 TB/s; one row per group is no better: 17.0 / 38.1 us), 4 for longer rows
+    const int rgt = ch == 2 && env_i("OQ_LETQ_FWD_RG", 2) == 2 ? 2 : 4;
+    const int64_t ngroups = (p.rows + rgt - 1) / rgt;
     const int64_t cap = (int64_t)n_cus() * env_i("OQ_LETQ_FWD_WGS", 8);
     const dim3 grid((unsigned)(ngroups < cap ? ngroups : cap));
     hipStream_t st = (hipStream_t)stream;
