@@ -8,9 +8,12 @@
 // front of a 4-bit rounding decision.  Here the projection's output (bf16 or fp32) is rotated in registers and
 // quantised at once; the backward recomputes the rotation, applies the quantiser's closed-form gradient
 // (oq_quant_dev.h arithmetic: same scale / zero-point / rounding as every other quantiser kernel) and the transposed
-// rotation.  A (token, head) segment is 16 lanes x 8 elements: its min / max and gradient sums are 4-step DPP
-// reductions, the rotation partner (element e +- 64) sits 8 lanes away -- loaded as a second 16-byte vector in the
-// forward, fetched with one DPP row rotation per element in the backward.  Four segments per wave instruction.
+// rotation.  A (token, head) segment is 4 lanes x 32 elements: lane l owns the 8-element chunks l, l+4, l+8, l+12, so
+// a load instruction reads 64 contiguous bytes per segment, the rotation partner (element e +- 64 = chunk j +- 8) is
+// in the SAME lane's registers (no second load, no cross-lane traffic), min / max / gradient sums are 2-step DPP
+// reductions inside a quad, and the per-segment arithmetic (scale, zero-point, tie terms: ~150 instructions) is
+// amortised over 32 elements per lane instead of 8 (the first version used 16 lanes x 8 elements and spent more
+// instructions on the segment constants than on the elements).  Sixteen segments per wave instruction.
 #include "oq_common.h"
 #include "oq_quant_dev.h"
 
@@ -30,132 +33,161 @@ struct RQ {
     void* gx;
 };
 
-constexpr int HD = 128, LPS = 16;        // lanes per segment
+constexpr int HD = 128, LPS = 4, NC = 4;      // lanes per segment, chunks of 8 per lane
 
-__device__ __forceinline__ float ror8(float v) {      // value of the lane 8 places around inside the 16-lane row
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
-}
-
+// rotated (or plain) values of lane l's chunks; chunk c of lane l covers elements (c*4 + l)*8 .. +8
 template <typename TIN>
-__device__ __forceinline__ void rotated(const RQ& p, int64_t seg, int l, float (&x)[8]) {
+__device__ __forceinline__ void rotated(const RQ& p, int64_t seg, int l, float (&x)[NC][8]) {
     const TIN* px = reinterpret_cast<const TIN*>(p.x) + seg * HD;
-    Vec8<TIN>::load(px + l * 8, x);
-    if (p.cs) {
-        float xp[8], c[8], s[8];
-        Vec8<TIN>::load(px + (l ^ 8) * 8, xp);
-        const int64_t t = (seg / p.nh) % p.T;
-        Vec8<float>::load(p.cs + t * HD + l * 8, c);
-        Vec8<float>::load(p.sn + t * HD + l * 8, s);
-        const float sgn = l < 8 ? -1.f : 1.f;           // rotate_half = cat(-x2, x1)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) x[i] = x[i] * c[i] + (sgn * xp[i]) * s[i];
+    for (int c = 0; c < NC; ++c) Vec8<TIN>::load(px + (c * 4 + l) * 8, x[c]);
+    if (p.cs) {
+        const int64_t t = (seg / p.nh) % p.T;
+        float r[NC][8];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {                   // cos / sin repeat on the two halves of the head
+            float cv[8], sv[8];
+            Vec8<float>::load(p.cs + t * HD + (c * 4 + l) * 8, cv);
+            Vec8<float>::load(p.sn + t * HD + (c * 4 + l) * 8, sv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {               // rotate_half = cat(-x2, x1)
+                r[c][i] = x[c][i] * cv[i] + (-x[c + 2][i]) * sv[i];
+                r[c + 2][i] = x[c + 2][i] * cv[i] + x[c][i] * sv[i];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[c][i] = r[c][i];
     }
 }
 
 template <typename TIN, typename TOUT>
 __global__ void __launch_bounds__(256) ropeq_fwd_kernel(RQ p) {
-    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int lane = threadIdx.x & 63, l = lane & 3;
     const int64_t nseg = p.rows * p.nh;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const float Q = (float)((1 << p.nbits) - 1);
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
-    for (int64_t s0 = wave * 4; s0 < nseg; s0 += nwaves * 4) {
-        int64_t seg = s0 + (lane >> 4);
-        if (seg >= nseg) seg = nseg - 1;                // surplus groups redo the last segment (same values stored again)
-        float x[8];
+    for (int64_t s0 = wave * 16; s0 < nseg; s0 += nwaves * 16) {
+        int64_t seg = s0 + (lane >> 2);
+        if (seg >= nseg) seg = nseg - 1;                // surplus quads redo the last segment (same values stored again)
+        float x[NC][8];
         rotated<TIN>(p, seg, l, x);
-        float hi = -INFINITY, lo = INFINITY, bad = 0.f;
+        float hi = -INFINITY, lo = INFINITY;
+        uint64_t nanm = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            hi = vmax(hi, x[i]);
-            lo = vmin(lo, x[i]);
-            if (x[i] != x[i]) bad = 1.f;
-        }
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                hi = vmax3(hi, x[c][i], x[c][i + 1]);
+                lo = vmin3(lo, x[c][i], x[c][i + 1]);
+                nanm |= __builtin_amdgcn_fcmpf(x[c][i], x[c][i + 1], 8);      // FCMP_UNO: either one is NaN
+            }
+        float bad = ((nanm >> lane) & 1) ? 1.f : 0.f;
         hi = wave_max(hi, LPS);
         lo = wave_min(lo, LPS);
         bad = wave_max(bad, LPS);
         if (bad != 0.f) { hi = NAN; lo = NAN; }
         float inv_s = 0.f;
         const QP q = make_qp(hi, lo, false, 0.f, 0.f, p.nbits, 0, p.inv_q, &inv_s);
-        float yv[8];
-        if (q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad == 0.f) {
+        const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad == 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float tq;
-                const float rq = rne_div(x[i], q.s, inv_s, &tq);
-                yv[i] = (__builtin_amdgcn_fmed3f(rq + q.z, 0.f, Q) - q.z) * q.s;
-            }
-        } else {
+        for (int c = 0; c < NC; ++c) {
+            float yv[8];
+            if (regular) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v = rne_ste(x[i] / q.s) + q.z;
-                v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
-                yv[i] = (v - q.z) * q.s;
+                for (int i = 0; i < 8; ++i) {
+                    float tq;
+                    const float rq = rne_div(x[c][i], q.s, inv_s, &tq);
+                    yv[i] = (__builtin_amdgcn_fmed3f(rq + q.z, 0.f, Q) - q.z) * q.s;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float v = rne_ste(x[c][i] / q.s) + q.z;
+                    v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
+                    yv[i] = (v - q.z) * q.s;
+                }
             }
+            Vec8<TOUT>::store(ybase + seg * HD + (c * 4 + l) * 8, yv);
         }
-        Vec8<TOUT>::store(ybase + seg * HD + l * 8, yv);
-        p.scale[seg] = q.s;       // the 16 lanes of a segment store the same value
-        p.zp[seg] = q.z;
-        p.xmin[seg] = lo;
-        p.xmax[seg] = hi;
+        if (l == 0) {
+            p.scale[seg] = q.s;
+            p.zp[seg] = q.z;
+            p.xmin[seg] = lo;
+            p.xmax[seg] = hi;
+        }
     }
 }
 
 template <typename TIN, typename TG>
 __global__ void __launch_bounds__(256) ropeq_bwd_kernel(RQ p) {
-    const int lane = threadIdx.x & 63, l = lane & 15;
+    const int lane = threadIdx.x & 63, l = lane & 3;
     const int64_t nseg = p.rows * p.nh;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const float Q = (float)((1 << p.nbits) - 1);
     const TG* gbase = reinterpret_cast<const TG*>(p.g);
     TG* gxbase = reinterpret_cast<TG*>(p.gx);
-    for (int64_t s0 = wave * 4; s0 < nseg; s0 += nwaves * 4) {
-        int64_t seg = s0 + (lane >> 4);
+    for (int64_t s0 = wave * 16; s0 < nseg; s0 += nwaves * 16) {
+        int64_t seg = s0 + (lane >> 2);
         if (seg >= nseg) seg = nseg - 1;
-        float x[8], G[8];
+        float x[NC][8], gin[NC][8];
         rotated<TIN>(p, seg, l, x);
-        Vec8<TG>::load(gbase + seg * HD + l * 8, G);
         const float hi = p.xmax[seg], lo = p.xmin[seg];
         float inv_s = 0.f;
         const QP q = make_qp(hi, lo, false, 0.f, 0.f, p.nbits, 0, p.inv_q, &inv_s);
-        const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f;
-        float gs = 0.f, chi = 0.f, clo = 0.f, gin[8];
+        // scale == 0 (quirk Q1): round_ste turns x / 0 = +-inf into NaN; a NaN zero-point inside round(t) + z gives the same
+        // all-NaN segment without a per-element select ((r - t) + t == r for every finite t)
+        const float zr = q.s == 0.f ? NAN : q.z;
+        float gs = 0.f, chi = 0.f, clo = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float tq = x[i] * inv_s;
-            const float u = (regular ? rintf(tq) : rne_ste(tq)) + q.z;
-            const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
-            const bool in = qv == u;
-            gs = fmaf(G[i], (qv - q.z) - (in ? tq : 0.f), gs);
-            chi += x[i] == hi ? 1.f : 0.f;
-            clo += x[i] == lo ? 1.f : 0.f;
-            gin[i] = in ? G[i] : 0.f;
+        for (int c = 0; c < NC; ++c) {
+            float G[8];
+            Vec8<TG>::load(gbase + seg * HD + (c * 4 + l) * 8, G);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float tq = x[c][i] * inv_s;
+                const float u = rintf(tq) + zr;
+                const float qv = __builtin_amdgcn_fmed3f(u, 0.f, Q);
+                gin[c][i] = qv == u ? G[i] : 0.f;
+                gs = fmaf(G[i], qv - q.z, gs);
+                gs = fmaf(-gin[c][i], tq, gs);
+                chi += x[c][i] == hi ? 1.f : 0.f;
+                clo += x[c][i] == lo ? 1.f : 0.f;
+            }
         }
         gs = wave_sum(gs, LPS);
         chi = wave_sum(chi, LPS);
         clo = wave_sum(clo, LPS);
         const float tie_hi = (gs / Q) / chi, tie_lo = -(gs / Q) / clo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (x[i] == hi) gin[i] += tie_hi;
-            if (x[i] == lo) gin[i] += tie_lo;
-        }
-        if (p.cs) {
-            // transposed rotation: gx_e = g_e cos_e - sgn_e * g_partner * sin_e   (cos / sin are equal on both halves)
-            float c[8], s[8];
-            const int64_t t = (seg / p.nh) % p.T;
-            Vec8<float>::load(p.cs + t * HD + l * 8, c);
-            Vec8<float>::load(p.sn + t * HD + l * 8, s);
-            const float sgn = l < 8 ? -1.f : 1.f;
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const float gp = ror8(gin[i]);
-                gin[i] = gin[i] * c[i] + (-(sgn * gp)) * s[i];
+                if (x[c][i] == hi) gin[c][i] += tie_hi;
+                if (x[c][i] == lo) gin[c][i] += tie_lo;
+            }
+        if (p.cs) {
+            // transposed rotation: gx_e = g_e cos_e - sgn_e * g_partner * sin_e   (cos / sin are equal on both halves)
+            const int64_t t = (seg / p.nh) % p.T;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float cv[8], sv[8];
+                Vec8<float>::load(p.cs + t * HD + (c * 4 + l) * 8, cv);
+                Vec8<float>::load(p.sn + t * HD + (c * 4 + l) * 8, sv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float ga = gin[c][i], gb = gin[c + 2][i];
+                    gin[c][i] = ga * cv[i] + gb * sv[i];              // first half: sgn = -1, partner = second half
+                    gin[c + 2][i] = gb * cv[i] + (-ga) * sv[i];
+                }
             }
         }
-        Vec8<TG>::store(gxbase + seg * HD + l * 8, gin);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) Vec8<TG>::store(gxbase + seg * HD + (c * 4 + l) * 8, gin[c]);
     }
 }
 
@@ -172,7 +204,7 @@ int check(const char* fn, int64_t rows, int64_t T, int nh, int hd, int nbits, co
 }
 
 unsigned rq_grid(int64_t nseg) {
-    const int64_t need = (nseg + 15) / 16;          // 4 segments per wave, 4 waves per workgroup
+    const int64_t need = (nseg + 63) / 64;          // 16 segments per wave, 4 waves per workgroup
     return (unsigned)(need < 16384 ? need : 16384);
 }
 
