@@ -6,6 +6,8 @@ identical up to module names).
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -125,7 +127,13 @@ class QuantBlockMixin:
                 return mod.bias
             return wsh if mod.bias is None else f(mod.bias) + wsh
 
-        for mod, sp in specs.items():
+        # issue order: the attention projections' weights are quantised LAST-USED-FIRST (o, v, k, q), so that the ones the
+        # first GEMMs read are the most recently written and still sit in the 256 MB Infinity Cache (same kernels, same values)
+        order = list(specs.items())
+        if os.environ.get("OQ_WQ_ORDER", "1") != "0":
+            rank = {nm["o"]: 0, nm["v"]: 1, nm["k"]: 2, nm["q"]: 3}
+            order.sort(key=lambda it: rank.get(it[0], -1))
+        for mod, sp in order:
             if mod in mlp:
                 def make(mod=mod, sp=sp):
                     w_, ws_ = quant(mod, sp)
@@ -179,7 +187,11 @@ class QuantBlockMixin:
             lazy_mlp = bool(self.__dict__.get("_lazy_mlp_quant")) and not forked
             mlp = set(nm["fc1"]) | {nm["last"]} if lazy_mlp else set()
             with torch.cuda.stream(side):
-                for mod in self._quant_linears():
+                mods = list(self._quant_linears())
+                if os.environ.get("OQ_WQ_ORDER", "1") != "0":       # last-used-first, see _let_temporaries
+                    rank = {nm["o"]: 0, nm["v"]: 1, nm["k"]: 2, nm["q"]: 3}
+                    mods.sort(key=lambda m: rank.get(m, -1))
+                for mod in mods:
                     if mod in mlp:
                         def make(mod=mod):
                             mod.temp_weight, mod.temp_bias = mod.weight_quantizer.quantize(mod.weight, out_dtype=dt), mod.bias
