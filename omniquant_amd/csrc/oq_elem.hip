@@ -3,6 +3,8 @@
 // grid-stride, f32 math.
 // Reference lines: models/int_llama_layer.py:44-45,124-125,153-163; models/int_opt_layer.py:96,151-170,307;
 // quantize/omniquant.py:220-222.
+#include <cstdlib>
+
 #include "oq_common.h"
 
 namespace {
@@ -281,6 +283,55 @@ __global__ void __launch_bounds__(256) colsum_partial_kernel(const T* x, int64_t
     }
 }
 
+// One-launch variant for the row counts of a calibration sample (<= 8192 rows): a workgroup owns 64 columns and walks ALL
+// rows (thread = 8 columns x every 32nd row, four loads in flight), then folds its 32 row phases through LDS in a fixed
+// order.  64-172 workgroups stream 17-45 MB in ~5 us -- no faster than the slab kernel, but the second launch (another
+// ~5 us inside the hipGraph) is gone.
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_direct_kernel(const T* x, int64_t rows, int64_t cols, float* out) {
+    __shared__ float red[32][65];
+    const int cch = threadIdx.x & 7, ro = threadIdx.x >> 3;
+    const int64_t c0 = (int64_t)blockIdx.x * 64 + cch * 8;
+    float acc[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[u][i] = 0.f;
+    if (c0 < cols) {
+        int64_t r = ro;
+        for (; r + 96 < rows; r += 128) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Vec8<T>::load(x + (r + 32 * u) * cols + c0, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[u][i] += v[u][i];
+        }
+        for (; r < rows; r += 32) {
+            float v[8];
+            Vec8<T>::load(x + r * cols + c0, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[0][i] += v[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) red[ro][cch * 8 + i] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int64_t col = (int64_t)blockIdx.x * 64 + threadIdx.x;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; k += 4) {
+            a0 += red[k][threadIdx.x];
+            a1 += red[k + 1][threadIdx.x];
+            a2 += red[k + 2][threadIdx.x];
+            a3 += red[k + 3][threadIdx.x];
+        }
+        if (col < cols) out[col] = (a0 + a1) + (a2 + a3);
+    }
+}
+
 // out[c] = sum_k ws[k][c] in a fixed order: block = 64 columns x 4 slab groups; a thread adds the slabs k = sg, sg+4, ...
 // of its column with four independent accumulators (loads in flight), the groups are combined through LDS.
 __global__ void __launch_bounds__(256) colsum_final_kernel(const float* ws, int slabs, int64_t cols, float* out) {
@@ -429,6 +480,11 @@ extern "C" int oq_cast(const void* x, int src_dtype, void* y, int dst_dtype, int
     return OQ_OK;
 }
 
+static bool colsum_direct_enabled() {          // OQ_COLSUM_DIRECT=0: the two-launch slab kernels (A/B)
+    const char* v = getenv("OQ_COLSUM_DIRECT");
+    return !(v && v[0] == '0');
+}
+
 static int colsum_slabs(int64_t rows) {
     int64_t s = rows / 16;          // many small slabs: the partial kernel is latency-bound below ~2 workgroups per CU
     return (int)(s < 1 ? 1 : (s > COLSUM_MAX_SLABS ? COLSUM_MAX_SLABS : s));
@@ -444,6 +500,17 @@ extern "C" int oq_colsum(const void* x, int dtype, int64_t rows, int64_t cols, f
     OQ_CHECK_ARG(workspace_floats >= (int64_t)slabs * cols, "oq_colsum: workspace of %lld floats needed",
                  (long long)((int64_t)slabs * cols));
     hipStream_t st = (hipStream_t)stream;
+    if (rows <= 8192 && cols >= 2048 && colsum_direct_enabled()) {
+        const dim3 gd((unsigned)((cols + 63) / 64));
+        if (dtype == OQ_F32) hipLaunchKernelGGL((colsum_direct_kernel<float>), gd, dim3(256), 0, st, (const float*)x, rows, cols, out);
+        else if (dtype == OQ_BF16) hipLaunchKernelGGL((colsum_direct_kernel<bf16_t>), gd, dim3(256), 0, st, (const bf16_t*)x, rows, cols, out);
+        else {
+            oq_set_error("oq_colsum: dtype %d unsupported", dtype);
+            return OQ_E_UNSUPPORTED;
+        }
+        OQ_CHECK_LAUNCH("oq_colsum");
+        return OQ_OK;
+    }
     const dim3 grid((unsigned)((cols + 511) / 512), (unsigned)slabs);
     if (dtype == OQ_F32)
         hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, cols, workspace);

@@ -354,6 +354,29 @@ def test_adamw_step_fused_vs_torch():
     assert torch.equal(p, p1) and float(step) == 7.0
 
 
+@pytest.mark.parametrize("direct", ["1", "0"])
+def test_colsum_bias_gradient_kernels(direct, monkeypatch):
+    """oq_colsum (bias gradients): the one-launch kernel (a workgroup owns 64 columns and walks all rows) and the two-launch
+    slab kernels, against a float64 sum; ragged row counts, both dtypes, bit-identical on repetition."""
+    from omniquant_amd import _capi as C
+    monkeypatch.setenv("OQ_COLSUM_DIRECT", direct)
+    g = torch.Generator().manual_seed(5)
+    for rows, cols, dt in ((2048, 4096, torch.bfloat16), (2048, 11008, torch.bfloat16), (2047, 2048, torch.bfloat16),
+                           (97, 4096, torch.float32), (16, 512, torch.bfloat16), (9000, 2048, torch.float32), (7, 64, torch.float32)):
+        x = torch.randn(rows, cols, generator=g).to(dt).to(DEV)
+        ws_n = C.size_call("oq_colsum_workspace", rows, cols)
+        ws = torch.empty(ws_n, device=DEV)
+        outs = []
+        for _ in range(2):
+            out = torch.full((cols,), float("nan"), device=DEV)
+            C.call("oq_colsum", C.ptr(x), C.dt(x), rows, cols, C.fptr(out), C.fptr(ws), ws_n, C.stream())
+            outs.append(out)
+        want = x.double().sum(0)
+        err = float((outs[0].double() - want).abs().max())
+        assert err <= 2e-6 * float(x.double().abs().sum(0).max()) + 1e-6, (rows, cols, dt, err)
+        assert torch.equal(outs[0], outs[1])
+
+
 def test_bad_arguments_raise():
     """Error convention of the boundary: negative rc -> OQError with the library's message; CPU tensors refused."""
     from omniquant_amd import ops, OQError, _capi as C
