@@ -67,6 +67,30 @@ int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int
                      float* workspace, int64_t workspace_floats, void* stream);
 int64_t oq_fakequant_bwd_workspace(int64_t rows, int64_t cols);
 
+/* Several weight matrices per call: what models/int_llama_layer.py:279-307 does matrix after matrix (smooth_*_temporary +
+ * weight_quantizer for q, k, v, o; quantize/quantizer.py:108-147 and models/transformation.py:24-69 and their autograd).
+ * Same arguments as oq_fakequant_fwd / oq_fakequant_bwd, one struct per matrix; same results as calling those in order.
+ * When all n (<= 4) problems are LET weights of one row length and one dtype pair the work is ONE launch per direction
+ * plus one launch for all column reductions; otherwise the matrices are processed one by one. */
+typedef struct {
+    const void* w; int w_dtype; int64_t rows, cols, seg; int nbits, symmetric;
+    const float *col_mul, *row_div, *row_mul, *shift, *up, *low;
+    void* y; int y_dtype;
+    float *scale, *zp, *xmin, *xmax, *wshift;
+} oq_fakequant_fwd_args;
+typedef struct {
+    const void* w; int w_dtype; int64_t rows, cols, seg; int nbits, symmetric;
+    const float *col_mul, *row_div, *row_mul, *shift, *up, *low, *xmin, *xmax;
+    const void* g; int g_dtype;
+    const float* g_wshift;
+    float *g_up, *g_low;
+    void* gx; int gx_dtype;
+    float *g_col_mul, *g_shift, *g_row_div, *g_row_mul, *workspace;
+    int64_t workspace_floats;
+} oq_fakequant_bwd_args;
+int oq_fakequant_fwd_multi(const oq_fakequant_fwd_args* a, int n, void* stream);
+int oq_fakequant_bwd_multi(const oq_fakequant_bwd_args* a, int n, void* stream);
+
 /* ---- QuantLinear / QuantMatMul GEMM (quantize/int_linear.py:62 F.linear; quantize/int_matmul.py:41-43
  * torch.matmul / torch.bmm, and their autograd: dgrad + wgrad) -------------------------------------------
  *   C[b][m][n] = alpha * sum_k A(b,m,k) * B(b,n,k) + bias[n]

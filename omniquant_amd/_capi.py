@@ -57,6 +57,28 @@ SIGNATURES = {
     "oq_let_vectors_bwd": [_i64] + [_vp] * 39,
 }
 
+
+
+class FakeQuantFwdArgs(ctypes.Structure):
+    """oq_fakequant_fwd_args of include/oq_hip.h (same fields, same order as oq_fakequant_fwd's parameters)."""
+    _fields_ = [("w", _vp), ("w_dtype", _i32), ("rows", _i64), ("cols", _i64), ("seg", _i64), ("nbits", _i32),
+                ("symmetric", _i32), ("col_mul", _vp), ("row_div", _vp), ("row_mul", _vp), ("shift", _vp), ("up", _vp),
+                ("low", _vp), ("y", _vp), ("y_dtype", _i32), ("scale", _vp), ("zp", _vp), ("xmin", _vp), ("xmax", _vp),
+                ("wshift", _vp)]
+
+
+class FakeQuantBwdArgs(ctypes.Structure):
+    """oq_fakequant_bwd_args of include/oq_hip.h."""
+    _fields_ = [("w", _vp), ("w_dtype", _i32), ("rows", _i64), ("cols", _i64), ("seg", _i64), ("nbits", _i32),
+                ("symmetric", _i32), ("col_mul", _vp), ("row_div", _vp), ("row_mul", _vp), ("shift", _vp), ("up", _vp),
+                ("low", _vp), ("xmin", _vp), ("xmax", _vp), ("g", _vp), ("g_dtype", _i32), ("g_wshift", _vp),
+                ("g_up", _vp), ("g_low", _vp), ("gx", _vp), ("gx_dtype", _i32), ("g_col_mul", _vp), ("g_shift", _vp),
+                ("g_row_div", _vp), ("g_row_mul", _vp), ("workspace", _vp), ("workspace_floats", _i64)]
+
+
+SIGNATURES["oq_fakequant_fwd_multi"] = [_vp, _i32, _vp]
+SIGNATURES["oq_fakequant_bwd_multi"] = [_vp, _i32, _vp]
+
 # functions returning a size instead of an error code
 SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64],
               "oq_attn_supported": [_i32, _i64, _i32, _i32], "oq_act_stats_workspace": [_i64, _i64],

@@ -133,14 +133,15 @@ class QuantBlockMixin:
         if os.environ.get("OQ_WQ_ORDER", "1") != "0":
             rank = {nm["o"]: 0, nm["v"]: 1, nm["k"]: 2, nm["q"]: 3}
             order.sort(key=lambda it: rank.get(it[0], -1))
-        for mod, sp in order:
-            if mod in mlp:
-                def make(mod=mod, sp=sp):
-                    w_, ws_ = quant(mod, sp)
-                    mod.temp_weight, mod.temp_bias = w_, mlp_bias(mod, ws_)
-                lazy[mod] = make
-            else:
-                wq[mod], ws[mod] = quant(mod, sp)
+        with ops.WeightQuantBatch():        # the weights quantised here and now (q, k, v, o) share one launch per direction
+            for mod, sp in order:
+                if mod in mlp:
+                    def make(mod=mod, sp=sp):
+                        w_, ws_ = quant(mod, sp)
+                        mod.temp_weight, mod.temp_bias = w_, mlp_bias(mod, ws_)
+                    lazy[mod] = make
+                else:
+                    wq[mod], ws[mod] = quant(mod, sp)
         q, k, v, o, ln1, ln2 = nm["q"], nm["k"], nm["v"], nm["o"], nm["ln1"], nm["ln2"]
         ln1_tw, ln1_tb, ln2_tw, ln2_tb, b_q, b_k, b_v, b_o = ops.LetVectorsFn.apply(
             self.qkv_smooth_scale, self.qkv_smooth_shift, self.out_smooth_scale, self.out_smooth_shift,

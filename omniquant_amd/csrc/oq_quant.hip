@@ -534,8 +534,7 @@ __global__ void __launch_bounds__(512) fq_bwd_kernel(FQ p) {
 // out[c] = sum_b part[b][c]   (deterministic: fixed order, no atomics).  blockIdx.y selects the vector
 // (0: g_col_mul, 1: g_shift).  A workgroup owns 16 columns: 16 row-groups x 16 columns of lanes, 8 independent
 // accumulators per lane (8 loads in flight), then one LDS tree over the row-groups.
-__global__ void __launch_bounds__(256) colreduce_kernel(const float* part, int nblocks, int64_t cols, float* out0,
-                                                        float* out1) {
+__device__ __forceinline__ void colreduce_body(const float* part, int nblocks, int64_t cols, float* out0, float* out1) {
     const float* src = part + (int64_t)blockIdx.y * nblocks * cols;
     float* out = blockIdx.y == 0 ? out0 : out1;
     if (!out) return;
@@ -567,6 +566,24 @@ __global__ void __launch_bounds__(256) colreduce_kernel(const float* part, int n
         for (int k = 0; k < 16; ++k) s += red[k][cl];
         out[c] = s;
     }
+}
+
+__global__ void __launch_bounds__(256) colreduce_kernel(const float* part, int nblocks, int64_t cols, float* out0,
+                                                        float* out1) {
+    colreduce_body(part, nblocks, cols, out0, out1);
+}
+
+// the column reductions of several matrices (oq_fakequant_bwd_multi) in one launch: blockIdx.z selects the matrix
+constexpr int OQ_WQ_MAX_ = 4;
+struct ColRedMulti {
+    const float* part[OQ_WQ_MAX_];
+    float* out0[OQ_WQ_MAX_];
+    float* out1[OQ_WQ_MAX_];
+    int nblocks[OQ_WQ_MAX_];
+};
+__global__ void __launch_bounds__(256) colreduce_multi_kernel(ColRedMulti m, int64_t cols) {
+    const int i = blockIdx.z;
+    if (m.nblocks[i] > 0) colreduce_body(m.part[i], m.nblocks[i], cols, m.out0[i], m.out1[i]);
 }
 
 // chunks per thread (1, 4 or 8) and threads per workgroup for a row of `cols` elements: as many waves as the row
@@ -962,6 +979,97 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
         hipLaunchKernelGGL(colreduce_kernel, rg, dim3(256), 0, (hipStream_t)stream, workspace, (int)grid, cols, g_col_mul, g_shift);
     }
     OQ_CHECK_LAUNCH("oq_fakequant_bwd");
+    return OQ_OK;
+}
+
+// ---- several weight matrices per call (include/oq_hip.h: oq_fakequant_fwd_multi / oq_fakequant_bwd_multi) -------------------
+// Same results as calling the single-matrix entry points in order; ONE launch per direction (plus one for the column
+// reductions) when all problems are LET weights of one row length the row-group kernels take.
+extern "C" int oq_fakequant_fwd_multi(const oq_fakequant_fwd_args* a, int n, void* stream) {
+    OQ_CHECK_ARG(a && n > 0, "oq_fakequant_fwd_multi: bad args");
+    if (n > 1 && n <= OQ_WQ_MAX_) {
+        FQ ps[OQ_WQ_MAX_];
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i) {
+            const oq_fakequant_fwd_args& t = a[i];
+            ok = !needs_generic(t.cols, t.seg) && check_shape("oq_fakequant_fwd_multi", t.rows, t.cols, t.seg, t.nbits) == OQ_OK &&
+                 t.w && t.y && t.scale && t.zp && t.xmin && t.xmax && oq_aligned16(t.w) && oq_aligned16(t.y) &&
+                 oq_aligned16(t.col_mul) && oq_aligned16(t.shift) && ((t.up == nullptr) == (t.low == nullptr)) &&
+                 (!t.wshift || t.shift) && t.w_dtype == a[0].w_dtype && t.y_dtype == a[0].y_dtype;
+            if (!ok) break;
+            FQ p{};
+            p.w = t.w; p.rows = t.rows; p.cols = t.cols; p.seg = t.seg; p.nbits = t.nbits; p.symmetric = t.symmetric;
+            p.inv_q = 1.0f / (float)((1 << t.nbits) - 1);
+            p.col_mul = t.col_mul; p.row_div = t.row_div; p.row_mul = t.row_mul; p.shift = t.wshift ? t.shift : nullptr;
+            p.up = t.up; p.low = t.low; p.y = t.y; p.scale = t.scale; p.zp = t.zp; p.xmin = t.xmin; p.xmax = t.xmax;
+            p.wshift = t.wshift;
+            ps[i] = p;
+        }
+        if (ok) {
+            const int rc = oq_letq_fwd_multi(ps, n, a[0].w_dtype, a[0].y_dtype, stream);
+            if (rc <= 0) return rc;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const oq_fakequant_fwd_args& t = a[i];
+        const int rc = oq_fakequant_fwd(t.w, t.w_dtype, t.rows, t.cols, t.seg, t.nbits, t.symmetric, t.col_mul, t.row_div, t.row_mul,
+                                        t.shift, t.up, t.low, t.y, t.y_dtype, t.scale, t.zp, t.xmin, t.xmax, t.wshift, stream);
+        if (rc) return rc;
+    }
+    return OQ_OK;
+}
+
+extern "C" int oq_fakequant_bwd_multi(const oq_fakequant_bwd_args* a, int n, void* stream) {
+    OQ_CHECK_ARG(a && n > 0, "oq_fakequant_bwd_multi: bad args");
+    if (n > 1 && n <= OQ_WQ_MAX_) {
+        FQ ps[OQ_WQ_MAX_];
+        int64_t wsf[OQ_WQ_MAX_], parts[OQ_WQ_MAX_];
+        bool ok = true;
+        for (int i = 0; i < n && ok; ++i) {
+            const oq_fakequant_bwd_args& t = a[i];
+            ok = !needs_generic(t.cols, t.seg) && check_shape("oq_fakequant_bwd_multi", t.rows, t.cols, t.seg, t.nbits) == OQ_OK &&
+                 t.w && t.g && t.xmin && t.xmax && oq_aligned16(t.w) && oq_aligned16(t.g) && oq_aligned16(t.col_mul) && !t.gx &&
+                 ((t.up == nullptr) == (t.low == nullptr)) && (!t.g_shift || t.g_wshift) && (!t.g_col_mul || t.col_mul) &&
+                 (!t.g_row_div || t.row_div) && (!t.g_row_mul || t.row_mul) && t.w_dtype == a[0].w_dtype && t.g_dtype == a[0].g_dtype;
+            if (!ok) break;
+            FQ p{};
+            p.w = t.w; p.rows = t.rows; p.cols = t.cols; p.seg = t.seg; p.nbits = t.nbits; p.symmetric = t.symmetric;
+            p.inv_q = 1.0f / (float)((1 << t.nbits) - 1);
+            p.col_mul = t.col_mul; p.row_div = t.row_div; p.row_mul = t.row_mul; p.shift = t.shift; p.up = t.up; p.low = t.low;
+            p.g = t.g; p.g_wshift = t.g_wshift; p.g_up = t.g_up; p.g_low = t.g_low; p.gx = nullptr;
+            p.xmin = const_cast<float*>(t.xmin); p.xmax = const_cast<float*>(t.xmax);
+            p.g_col_mul = t.g_col_mul; p.g_shift = t.g_shift; p.g_row_div = t.g_row_div; p.g_row_mul = t.g_row_mul;
+            p.ws = t.workspace;
+            ps[i] = p;
+            wsf[i] = t.workspace_floats;
+        }
+        if (ok) {
+            const int rc = oq_letq_bwd_multi(ps, n, a[0].w_dtype, a[0].g_dtype, wsf, parts, stream);
+            if (rc < 0) return rc;
+            if (rc == 0) {
+                ColRedMulti m{};
+                bool any = false;
+                for (int i = 0; i < n; ++i) {
+                    m.part[i] = a[i].workspace; m.out0[i] = a[i].g_col_mul; m.out1[i] = a[i].g_shift; m.nblocks[i] = (int)parts[i];
+                    any = any || parts[i] > 0;
+                }
+                if (any) {
+                    const dim3 rg((unsigned)((a[0].cols + 15) / 16), 2, (unsigned)n);
+                    hipLaunchKernelGGL(colreduce_multi_kernel, rg, dim3(256), 0, (hipStream_t)stream, m, a[0].cols);
+                    OQ_CHECK_LAUNCH("oq_fakequant_bwd_multi(colreduce)");
+                }
+                return OQ_OK;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const oq_fakequant_bwd_args& t = a[i];
+        const int rc = oq_fakequant_bwd(t.w, t.w_dtype, t.rows, t.cols, t.seg, t.nbits, t.symmetric, t.col_mul, t.row_div, t.row_mul,
+                                        t.shift, t.up, t.low, t.xmin, t.xmax, t.g, t.g_dtype, t.g_wshift, t.g_up, t.g_low, t.gx,
+                                        t.gx_dtype, t.g_col_mul, t.g_shift, t.g_row_div, t.g_row_mul, t.workspace, t.workspace_floats,
+                                        stream);
+        if (rc) return rc;
+    }
     return OQ_OK;
 }
 

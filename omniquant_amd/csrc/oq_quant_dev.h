@@ -220,4 +220,6 @@ int oq_rowq_fwd(const FQ& p, int w_dtype, int y_dtype, void* stream);
 int oq_rowq_bwd(const FQ& p, int w_dtype, int g_dtype, float* workspace, int64_t workspace_floats, int64_t* partial_rows,
                 void* stream);
 int64_t oq_letq_bwd_blocks(int64_t rows);
+int oq_letq_fwd_multi(const FQ* ps, int n, int w_dtype, int y_dtype, void* stream);
+int oq_letq_bwd_multi(FQ* ps, int n, int w_dtype, int g_dtype, const int64_t* workspace_floats, int64_t* parts, void* stream);
 int64_t oq_rowq_bwd_blocks(int64_t rows, int64_t cols);     // workgroups that write column partials (workspace rows)

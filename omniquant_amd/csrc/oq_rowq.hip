@@ -487,11 +487,17 @@ struct RowQ {       // per-row constants handed from the finalising wave to ever
 
 // MODE: bit 0 = row_div present, bit 1 = row_mul present (compile-time: no per-element selects for them)
 // RGT rows per group: 4, or 2 for matrices of few row groups (half the registers per wave, twice the workgroups)
+template <int RGT>
+struct LetqFwdSmem {        // declared once per KERNEL (a body instantiated per row mode would otherwise get one copy each)
+    float part[4][RGT][4];
+    float qps[RGT][4];
+};
+
 template <typename TIN, typename TOUT, int CH, int MODE, int RGT>
-__global__ void __launch_bounds__(256, CH <= 2 ? (RGT == 2 ? 4 : LETQ_FWD_WPE) : 2) letq_fwd_kernel(FQ p) {
+__device__ __forceinline__ void letq_fwd_body(const FQ& p, const int bid, const int nb, LetqFwdSmem<RGT>& sm) {
     constexpr bool has_rd = (MODE & 1) != 0, has_rm = (MODE & 2) != 0;
-    __shared__ __attribute__((aligned(16))) float part[4][RGT][4];
-    __shared__ __attribute__((aligned(16))) float qps[RGT][4];
+    float (&part)[4][RGT][4] = sm.part;
+    float (&qps)[RGT][4] = sm.qps;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int K = (int)p.cols;
@@ -514,7 +520,7 @@ __global__ void __launch_bounds__(256, CH <= 2 ? (RGT == 2 ? 4 : LETQ_FWD_WPE) :
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
     const bool lwc = p.up != nullptr;
     const int64_t ngroups = (p.rows + RGT - 1) / RGT;
-    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    for (int64_t g = bid; g < ngroups; g += nb) {
         const int64_t r0 = g * RGT;
         // ---- phase A: load + transform this wave's columns of the 4 rows, per-row partial min / max / NaN / w@shift ----
         Raw8<TIN> raw[RGT][CH];
@@ -624,16 +630,55 @@ __global__ void __launch_bounds__(256, CH <= 2 ? (RGT == 2 ? 4 : LETQ_FWD_WPE) :
     }
 }
 
+template <typename TIN, typename TOUT, int CH, int MODE, int RGT>
+__global__ void __launch_bounds__(256, CH <= 2 ? (RGT == 2 ? 4 : LETQ_FWD_WPE) : 2) letq_fwd_kernel(FQ p) {
+    __shared__ __attribute__((aligned(16))) LetqFwdSmem<RGT> sm;
+    letq_fwd_body<TIN, TOUT, CH, MODE, RGT>(p, (int)blockIdx.x, (int)gridDim.x, sm);
+}
+
+// Several weight matrices of one shape class (same row length, dtypes) in ONE launch: workgroup ranges [start[i],
+// start[i+1]) belong to matrix i.  Four 67 MB problems launched one by one run at 3.9 TB/s each (ramp-up, tail and the
+// launch gap are paid four times), the same kernel on a 180 MB problem at 5.2 TB/s.
+constexpr int OQ_WQ_MAX = 4;
+struct MultiFQ {
+    FQ t[OQ_WQ_MAX];
+    int start[OQ_WQ_MAX + 1];
+    int mode[OQ_WQ_MAX];
+    int n;
+};
+
+template <typename TIN, typename TOUT, int CH, int RGT>
+__global__ void __launch_bounds__(256, CH <= 2 ? (RGT == 2 ? 4 : LETQ_FWD_WPE) : 2) letq_fwd_multi_kernel(MultiFQ m) {
+    __shared__ __attribute__((aligned(16))) LetqFwdSmem<RGT> sm;
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
+    const int bid = (int)blockIdx.x - m.start[i], nb = m.start[i + 1] - m.start[i];
+    switch (m.mode[i]) {
+        case 0: letq_fwd_body<TIN, TOUT, CH, 0, RGT>(m.t[i], bid, nb, sm); break;
+        case 1: letq_fwd_body<TIN, TOUT, CH, 1, RGT>(m.t[i], bid, nb, sm); break;
+        case 2: letq_fwd_body<TIN, TOUT, CH, 2, RGT>(m.t[i], bid, nb, sm); break;
+        default: letq_fwd_body<TIN, TOUT, CH, 3, RGT>(m.t[i], bid, nb, sm); break;
+    }
+}
+
 // MODE: bit 0 = row_div present, bit 1 = row_mul present (compile-time: the element loop carries no selects for them)
-template <typename TIN, typename TG, int CH, int MODE>
-__global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kernel(FQ p) {
-    __shared__ __attribute__((aligned(16))) float part[4][RG][4];
-    __shared__ __attribute__((aligned(16))) float qps2[2][RG][12];    // by group parity: phase A of the next group overlaps phase D
-    __shared__ __attribute__((aligned(16))) float ties[RG][4];
+template <typename TIN, int CH>
+struct LetqBwdSmem {        // declared once per KERNEL (see LetqFwdSmem)
+    float part[4][RG][4];
+    float qps2[2][RG][12];    // by group parity: phase A of the next group overlaps phase D
+    float ties[RG][4];
     // 16-bit weights: a chunk that holds an amax / amin element is parked in LDS by the wave that met it (phase B) and read
     // back by the same wave in phase D, instead of being fetched from global memory a second time
+    Raw8<TIN> stash[sizeof(TIN) == 2 ? 4 * RG * CH * 64 : 1];
+};
+
+template <typename TIN, typename TG, int CH, int MODE>
+__device__ __forceinline__ void letq_bwd_body(const FQ& p, const int bid, const int nb, LetqBwdSmem<TIN, CH>& sm) {
+    float (&part)[4][RG][4] = sm.part;
+    float (&qps2)[2][RG][12] = sm.qps2;
+    float (&ties)[RG][4] = sm.ties;
     constexpr bool STASH = sizeof(TIN) == 2;
-    __shared__ __attribute__((aligned(16))) Raw8<TIN> stash[STASH ? 4 * RG * CH * 64 : 1];
+    Raw8<TIN>* stash = sm.stash;
     constexpr bool has_rd = (MODE & 1) != 0, has_rm = (MODE & 2) != 0;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -665,7 +710,7 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
     // register rings were measured: copies between ring slots wait for the load they move, and four statically
     // assigned slots cost 30 VGPRs and ran 15 % slower.)
     auto stream_row = [&](int64_t g, int k) -> int64_t {
-        const int64_t r = k < RG ? g * RG + k : (g + gridDim.x) * RG + (k - RG);
+        const int64_t r = k < RG ? g * RG + k : (g + nb) * RG + (k - RG);
         return r < p.rows ? r : p.rows - 1;        // past the end: a re-read of the last row nobody uses
     };
     // the same for the per-row constants phase A needs: those of the workgroup's next group are fetched one group ahead
@@ -685,16 +730,16 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
     Raw8<TIN> cw[CH];
     Raw8<TG> cg[CH];
     RowIn nxt{};
-    if ((int64_t)blockIdx.x < ngroups) {
-        nxt = fetch_row_in(blockIdx.x);
-        const int64_t ra = stream_row(blockIdx.x, 0);
+    if ((int64_t)bid < ngroups) {
+        nxt = fetch_row_in(bid);
+        const int64_t ra = stream_row(bid, 0);
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             cw[j].load(wbase + ra * K + cc[j]);
             cg[j].load(gbase + ra * K + cc[j]);
         }
     }
-    for (int64_t g = blockIdx.x; g < ngroups; g += gridDim.x, par ^= 1) {
+    for (int64_t g = bid; g < ngroups; g += nb, par ^= 1) {
         const int64_t r0 = g * RG;
         float (*qps)[12] = qps2[par];
         auto row_of = [&](int rr) { return r0 + rr < p.rows ? r0 + rr : p.rows - 1; };
@@ -703,7 +748,7 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
         float my_rm = 1.f, my_rmrd = 1.f;
         {
             const RowIn in = nxt;
-            nxt = fetch_row_in(g + gridDim.x);      // lands under phases B .. D
+            nxt = fetch_row_in(g + nb);      // lands under phases B .. D
             const float hi = in.hi, lo = in.lo, rd = in.rd, rm = in.rm, gws = in.gws;
             const float inv_rd = 1.f / rd;
             float inv_s = 0.f;
@@ -868,8 +913,8 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
         // (the next group writes the OTHER qps buffer; `part` and `ties` are rewritten only behind the next group's barriers)
     }
     if (need_cm || need_sh) {
-        float* wcm = p.ws + (int64_t)blockIdx.x * K;
-        float* wsh = p.ws + ((int64_t)gridDim.x + blockIdx.x) * K;
+        float* wcm = p.ws + (int64_t)bid * K;
+        float* wsh = p.ws + ((int64_t)nb + bid) * K;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (valid[j]) {
@@ -877,6 +922,26 @@ __global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kern
                 if (need_sh) Vec8<float>::store(wsh + cc[j], acc_sh[j]);
             }
         }
+    }
+}
+
+template <typename TIN, typename TG, int CH, int MODE>
+__global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_kernel(FQ p) {
+    __shared__ __attribute__((aligned(16))) LetqBwdSmem<TIN, CH> sm;
+    letq_bwd_body<TIN, TG, CH, MODE>(p, (int)blockIdx.x, (int)gridDim.x, sm);
+}
+
+template <typename TIN, typename TG, int CH>
+__global__ void __launch_bounds__(256, CH <= 2 ? LETQ_BWD_WPE : 2) letq_bwd_multi_kernel(MultiFQ m) {
+    __shared__ __attribute__((aligned(16))) LetqBwdSmem<TIN, CH> sm;
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.start[i + 1]) ++i;
+    const int bid = (int)blockIdx.x - m.start[i], nb = m.start[i + 1] - m.start[i];
+    switch (m.mode[i]) {
+        case 0: letq_bwd_body<TIN, TG, CH, 0>(m.t[i], bid, nb, sm); break;
+        case 1: letq_bwd_body<TIN, TG, CH, 1>(m.t[i], bid, nb, sm); break;
+        case 2: letq_bwd_body<TIN, TG, CH, 2>(m.t[i], bid, nb, sm); break;
+        default: letq_bwd_body<TIN, TG, CH, 3>(m.t[i], bid, nb, sm); break;
     }
 }
 
@@ -978,6 +1043,98 @@ static int letq_fwd(const FQ& p, int ch, int w_dtype, int y_dtype, void* stream)
         default: return 1;
     }
     OQ_CHECK_LAUNCH("oq_fakequant_fwd(letq)");
+    return OQ_OK;
+}
+
+static bool letq_fwd_eligible(const FQ& p) {
+    return p.seg == p.cols && env_i("OQ_ROWQ", 1) != 0 && (p.col_mul || p.row_div || p.row_mul || p.shift) && letq_ch(p.cols) != 0;
+}
+
+// n weight matrices in one launch (see MultiFQ).  Returns 0 when launched, 1 when the problems are not one shape class of
+// the row-group LET kernels (the caller then launches them one by one), or a negative OQ_E_* code.
+int oq_letq_fwd_multi(const FQ* ps, int n, int w_dtype, int y_dtype, void* stream) {
+    if (n < 2 || n > OQ_WQ_MAX || env_i("OQ_WQ_MULTI", 1) == 0) return 1;
+    const int ch = letq_fwd_eligible(ps[0]) ? letq_ch(ps[0].cols) : 0;
+    if (ch != 2) return 1;
+    for (int i = 0; i < n; ++i)
+        if (!letq_fwd_eligible(ps[i]) || ps[i].cols != ps[0].cols || ps[i].nbits != ps[0].nbits) return 1;
+    const int rgt = env_i("OQ_LETQ_FWD_RG", 2) == 2 ? 2 : 4;
+    MultiFQ m{};
+    m.n = n;
+    const int64_t cap = (int64_t)n_cus() * env_i("OQ_LETQ_FWD_WGS", 8);
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        m.t[i] = ps[i];
+        m.mode[i] = (ps[i].row_div ? 1 : 0) | (ps[i].row_mul ? 2 : 0);
+        const int64_t ng = (ps[i].rows + rgt - 1) / rgt;
+        m.start[i] = (int)tot;
+        tot += ng < cap ? ng : cap;
+    }
+    m.start[n] = (int)tot;
+    const dim3 grid((unsigned)tot);
+    hipStream_t st = (hipStream_t)stream;
+#define LQ_FWD_MULTI(TIN, TOUT)                                                                              \
+    do {                                                                                                     \
+        if (rgt == 2) hipLaunchKernelGGL((letq_fwd_multi_kernel<TIN, TOUT, 2, 2>), grid, dim3(256), 0, st, m); \
+        else hipLaunchKernelGGL((letq_fwd_multi_kernel<TIN, TOUT, 2, 4>), grid, dim3(256), 0, st, m);        \
+    } while (0)
+    switch (w_dtype * 3 + y_dtype) {
+        case OQ_F32 * 3 + OQ_F32: LQ_FWD_MULTI(float, float); break;
+        case OQ_F32 * 3 + OQ_BF16: LQ_FWD_MULTI(float, bf16_t); break;
+        case OQ_F16 * 3 + OQ_F32: LQ_FWD_MULTI(f16_t, float); break;
+        case OQ_F16 * 3 + OQ_BF16: LQ_FWD_MULTI(f16_t, bf16_t); break;
+        case OQ_BF16 * 3 + OQ_BF16: LQ_FWD_MULTI(bf16_t, bf16_t); break;
+        default: return 1;
+    }
+    OQ_CHECK_LAUNCH("oq_fakequant_fwd_multi(letq)");
+    return OQ_OK;
+}
+
+static bool letq_bwd_eligible(const FQ& p) {
+    const bool let = p.col_mul || p.row_div || p.row_mul || p.g_col_mul || p.g_shift || p.g_row_div || p.g_row_mul;
+    return p.seg == p.cols && env_i("OQ_ROWQ", 1) != 0 && let && !p.gx && letq_ch(p.cols) != 0;
+}
+
+// Backward counterpart: ps[i].ws must already point at matrix i's workspace (2 * parts[i] * cols floats, checked by the
+// caller); parts[i] receives the number of partial rows matrix i's workgroups wrote (0: no column gradients asked for).
+int oq_letq_bwd_multi(FQ* ps, int n, int w_dtype, int g_dtype, const int64_t* workspace_floats, int64_t* parts, void* stream) {
+    if (n < 2 || n > OQ_WQ_MAX || env_i("OQ_WQ_MULTI", 1) == 0) return 1;
+    const int ch = letq_bwd_eligible(ps[0]) ? letq_ch(ps[0].cols) : 0;
+    if (ch != 2) return 1;
+    for (int i = 0; i < n; ++i)
+        if (!letq_bwd_eligible(ps[i]) || ps[i].cols != ps[0].cols || ps[i].nbits != ps[0].nbits) return 1;
+    MultiFQ m{};
+    m.n = n;
+    int64_t tot = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t nblk = oq_letq_bwd_blocks(ps[i].rows);
+        parts[i] = 0;
+        if (ps[i].g_col_mul || ps[i].g_shift) {
+            OQ_CHECK_ARG(ps[i].ws && workspace_floats[i] >= 2 * nblk * ps[i].cols,
+                         "oq_fakequant_bwd_multi: workspace of %lld floats needed (oq_fakequant_bwd_workspace)",
+                         (long long)(2 * nblk * ps[i].cols));
+            parts[i] = nblk;
+        } else {
+            ps[i].ws = nullptr;
+        }
+        m.t[i] = ps[i];
+        m.mode[i] = (ps[i].row_div ? 1 : 0) | (ps[i].row_mul ? 2 : 0);
+        m.start[i] = (int)tot;
+        tot += nblk;
+    }
+    m.start[n] = (int)tot;
+    const dim3 grid((unsigned)tot);
+    hipStream_t st = (hipStream_t)stream;
+#define LQ_BWD_MULTI(TIN, TG) hipLaunchKernelGGL((letq_bwd_multi_kernel<TIN, TG, 2>), grid, dim3(256), 0, st, m)
+    switch (w_dtype * 3 + g_dtype) {
+        case OQ_F32 * 3 + OQ_F32: LQ_BWD_MULTI(float, float); break;
+        case OQ_F32 * 3 + OQ_BF16: LQ_BWD_MULTI(float, bf16_t); break;
+        case OQ_F16 * 3 + OQ_F32: LQ_BWD_MULTI(f16_t, float); break;
+        case OQ_F16 * 3 + OQ_BF16: LQ_BWD_MULTI(f16_t, bf16_t); break;
+        case OQ_BF16 * 3 + OQ_BF16: LQ_BWD_MULTI(bf16_t, bf16_t); break;
+        default: return 1;
+    }
+    OQ_CHECK_LAUNCH("oq_fakequant_bwd_multi(letq)");
     return OQ_OK;
 }
 

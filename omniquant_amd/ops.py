@@ -4,6 +4,7 @@ Each Function's forward AND backward are hand-written HIP kernels; PyTorch only 
 the graph.  Activations are float32 (parity mode: exact-f32 MFMA) or bfloat16 (production: bf16 MFMA).
 """
 import math
+import ctypes
 import os
 
 import torch
@@ -28,6 +29,77 @@ def _f32(t):
 # ------------------------------------------------------------------------------------------------------
 # UniformAffineQuantizer core (+ LET weight re-parameterisation)
 # ------------------------------------------------------------------------------------------------------
+class WeightQuantBatch:
+    """`with WeightQuantBatch():` -- the FakeQuantFn calls made inside (the LET weights of one shape: q, k, v, o) are launched
+    as ONE multi-matrix kernel when the block ends (oq_fakequant_fwd_multi), and their backward calls as one launch plus one
+    launch for all column reductions (oq_fakequant_bwd_multi) once the last of them has arrived -- or when
+    `flush_pending()` is called (optim.GradCollector.flush does, before anything reads the gradients).  Same kernels'
+    arithmetic, same values; four 67 MB problems stop paying ramp-up, tail and launch gap four times.  OQ_WQ_BATCH=0: off."""
+    active = None
+    pending = []          # batches whose backward has started but is not launched yet
+
+    def __init__(self):
+        self.fwd, self.bwd, self.keep = [], [], []
+        self.shape = None
+        self.enabled = os.environ.get("OQ_WQ_BATCH", "1") != "0"
+
+    def takes(self, w, cols, seg, col_mul, row_div, row_mul, shift):
+        if not self.enabled or seg != cols or w.dim() != 2 or len(self.fwd) >= 4:
+            return False
+        if col_mul is None and row_div is None and row_mul is None and shift is None:
+            return False
+        key = (tuple(w.shape), w.dtype, w.device)
+        if self.shape is None:
+            self.shape = key
+        return self.shape == key
+
+    def add_forward(self, args, keep):
+        self.fwd.append(args)
+        self.keep.append(keep)
+
+    def __enter__(self):
+        if WeightQuantBatch.active is not None:
+            raise C.OQError("WeightQuantBatch does not nest")
+        WeightQuantBatch.active = self
+        return self
+
+    def __exit__(self, *exc):
+        WeightQuantBatch.active = None
+        if self.fwd and exc[0] is None:
+            arr = (C.FakeQuantFwdArgs * len(self.fwd))()
+            for i, a in enumerate(self.fwd):
+                arr[i] = C.FakeQuantFwdArgs(*a)
+            C.call("oq_fakequant_fwd_multi", ctypes.addressof(arr), len(self.fwd), C.stream())
+        self.n = len(self.fwd)
+        self.fwd, self.keep = [], []
+        return False
+
+    def add_backward(self, args, keep):
+        if not self.bwd:
+            WeightQuantBatch.pending.append(self)
+            # a sibling that needs no gradient never arrives: whatever is still queued goes out when this backward pass ends
+            torch.autograd.Variable._execution_engine.queue_callback(WeightQuantBatch.flush_pending)
+        self.bwd.append(args)
+        self.keep.append(keep)
+        if len(self.bwd) == self.n:
+            self.flush_backward()
+
+    def flush_backward(self):
+        if self in WeightQuantBatch.pending:
+            WeightQuantBatch.pending.remove(self)
+        if self.bwd:
+            arr = (C.FakeQuantBwdArgs * len(self.bwd))()
+            for i, a in enumerate(self.bwd):
+                arr[i] = C.FakeQuantBwdArgs(*a)
+            C.call("oq_fakequant_bwd_multi", ctypes.addressof(arr), len(self.bwd), C.stream())
+        self.bwd, self.keep = [], []
+
+    @staticmethod
+    def flush_pending():
+        for b in list(WeightQuantBatch.pending):
+            b.flush_backward()
+
+
 class FakeQuantFn(torch.autograd.Function):
     """y = fake_quant(((w*col_mul)/row_div)*row_mul) over segments of `seg`; wshift = w @ shift.
 
@@ -47,10 +119,17 @@ class FakeQuantFn(torch.autograd.Function):
         xmax = torch.empty((nseg,), dtype=torch.float32, device=w.device)
         wshift = torch.empty((rows,), dtype=torch.float32, device=w.device) if shift is not None else None
         cm, rd, rm, sh, u, l = (_f32(t) for t in (col_mul, row_div, row_mul, shift, up, low))
-        C.call("oq_fakequant_fwd", C.ptr(w), C.dt(w), rows, cols, seg, nbits, int(symmetric),
-               C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l),
-               C.ptr(y), C._DT[out_dtype], C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.fptr(wshift),
-               C.stream())
+        fargs = (C.ptr(w), C.dt(w), rows, cols, seg, nbits, int(symmetric),
+                 C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l),
+                 C.ptr(y), C._DT[out_dtype], C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.fptr(wshift))
+        batch = WeightQuantBatch.active
+        ctx.batch = None
+        if batch is not None and batch.takes(w, cols, seg, col_mul, row_div, row_mul, shift):
+            # launched with its siblings when the `with` block ends (one multi-matrix launch); the outputs are not read before
+            batch.add_forward(fargs, (w, cm, rd, rm, sh, u, l, y, scale, zp, xmin, xmax, wshift))
+            ctx.batch = batch
+        else:
+            C.call("oq_fakequant_fwd", *fargs, C.stream())
         if stash is not None:
             stash["scale"], stash["zp"] = scale, zp
         ctx.save_for_backward(w, cm, rd, rm, sh, u, l, xmin, xmax)
@@ -95,10 +174,18 @@ class FakeQuantFn(torch.autograd.Function):
         if g_cm is not None or g_sh is not None:
             ws_n = C.size_call("oq_fakequant_bwd_workspace", rows, cols)
             ws = torch.empty((ws_n,), dtype=torch.float32, device=dev)
-        C.call("oq_fakequant_bwd", C.ptr(w), C.dt(w), rows, cols, seg, nbits, symmetric,
-               C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l), C.fptr(xmin), C.fptr(xmax),
-               C.ptr(gy), C.dt(gy), C.fptr(gws), C.fptr(g_up), C.fptr(g_low), C.ptr(gx), C.dt(gy),
-               C.fptr(g_cm), C.fptr(g_sh), C.fptr(g_rd), C.fptr(g_rm), C.fptr(ws), ws_n, C.stream())
+        bargs = (C.ptr(w), C.dt(w), rows, cols, seg, nbits, symmetric,
+                 C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l), C.fptr(xmin), C.fptr(xmax),
+                 C.ptr(gy), C.dt(gy), C.fptr(gws), C.fptr(g_up), C.fptr(g_low), C.ptr(gx), C.dt(gy),
+                 C.fptr(g_cm), C.fptr(g_sh), C.fptr(g_rd), C.fptr(g_rm), C.fptr(ws), ws_n)
+        routed = all(r is not None for r, t in zip((r_cm, r_rd, r_rm, r_sh, r_up, r_low), (g_cm, g_rd, g_rm, g_sh, g_up, g_low))
+                     if t is not None)
+        if ctx.batch is not None and gx is None and routed:
+            # deferred only when no gradient goes back to autograd (AccumulateGrad would copy a buffer that is not filled yet):
+            # every consumer (the optimiser arena, optim.GradCollector.flush) runs after the batch is flushed
+            ctx.batch.add_backward(bargs, (w, cm, rd, rm, sh, u, l, xmin, xmax, gy, gws, g_up, g_low, g_cm, g_sh, g_rd, g_rm, ws))
+        else:
+            C.call("oq_fakequant_bwd", *bargs, C.stream())
         if gx is not None and gx.dtype != w.dtype:
             gx = gx.to(w.dtype)
         if r_up is not None:

@@ -39,6 +39,8 @@ class GradCollector:
         ent[1].append(partial.contiguous().view(-1))
 
     def flush(self):
+        from .ops import WeightQuantBatch
+        WeightQuantBatch.flush_pending()      # batched weight-quantiser backward launches whose siblings never arrived
         if not self.pending:
             return
         entries = list(self.pending.values())

@@ -377,6 +377,89 @@ def test_colsum_bias_gradient_kernels(direct, monkeypatch):
         assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("n_back", [4, 3])
+@pytest.mark.parametrize("routed", [True, False])
+def test_weight_quant_batch_matches_single_launches(n_back, routed):
+    """ops.WeightQuantBatch: the LET weights of one shape quantised in ONE multi-matrix launch per direction
+    (oq_fakequant_fwd_multi / oq_fakequant_bwd_multi) give bit-identical outputs and gradients to one launch per matrix;
+    a sibling whose gradient never arrives (n_back = 3) does not leave the others unlaunched.  routed: the gradients go to
+    the optimiser's sinks / collector (the engine's case, backward launches are merged too) or back to autograd (then the
+    backward launches stay separate: AccumulateGrad copies what it is handed at once)."""
+    from omniquant_amd import ops
+    rows, cols = 512, 4096
+    modes = [dict(rd=True), dict(rm=True), dict(rd=True), dict()]          # q, k, v, o
+
+    class Collector:
+        def __init__(self):
+            self.got = {}
+
+        def add(self, par, g):
+            self.got[par._name] = g
+
+    def run(batched):
+        outs, leaves = [], []
+        coll = Collector()
+        gen = torch.Generator().manual_seed(12)
+        ctxm = ops.WeightQuantBatch() if batched else None
+        if ctxm is not None:
+            ctxm.__enter__()
+        for i, m in enumerate(modes):
+            W = (torch.randn(rows, cols, generator=gen) * 0.02).half().to(DEV)
+            named = dict(cm=(torch.rand(cols, generator=gen) + 0.5), sh=torch.randn(cols, generator=gen),
+                         rd=(torch.rand(rows, generator=gen) + 0.5) if m.get("rd") else None,
+                         rm=(torch.rand(rows, generator=gen) + 0.5) if m.get("rm") else None,
+                         up=torch.full((rows, 1), 4.0), low=torch.full((rows, 1), 3.5))
+            t = {}
+            for k, v in named.items():
+                if v is None:
+                    t[k] = None
+                    continue
+                v = v.to(DEV).requires_grad_(True)
+                v._name = f"{i}.{k}"
+                if routed:
+                    v._oq_grad_sink = torch.zeros_like(v)
+                    v._oq_collector = coll
+                t[k] = v
+            y, ws = ops.fake_quant(W, 4, up=t["up"], low=t["low"], out_dtype=torch.bfloat16, col_mul=t["cm"], row_div=t["rd"],
+                                   row_mul=t["rm"], shift=t["sh"])
+            outs.append((y, ws))
+            leaves.append(t)
+        if ctxm is not None:
+            ctxm.__exit__(None, None, None)
+        gen2 = torch.Generator().manual_seed(13)
+        loss = 0.0
+        for i, (y, ws) in enumerate(outs[:n_back]):
+            G = torch.randn(rows, cols, generator=gen2).to(DEV)
+            gw = torch.randn(rows, generator=gen2).to(DEV)
+            loss = loss + (y.float() * G).sum() + (ws * gw).sum()
+        loss.backward()
+        ops.WeightQuantBatch.flush_pending()        # what optim.GradCollector.flush does first
+        torch.cuda.synchronize()
+        grads = {}
+        for i, t in enumerate(leaves):
+            for k, v in t.items():
+                if v is None:
+                    continue
+                if not routed:
+                    grads[v._name] = None if v.grad is None else v.grad.clone()
+                elif k in ("up", "low"):
+                    grads[v._name] = v._oq_grad_sink.clone()
+                else:
+                    grads[v._name] = coll.got.get(v._name)
+        return [(y.detach().clone(), ws.detach().clone()) for y, ws in outs], grads
+
+    o1, g1 = run(False)
+    o2, g2 = run(True)
+    for (ya, wa), (yb, wb) in zip(o1, o2):
+        assert torch.equal(ya, yb) and torch.equal(wa, wb)
+    assert g1.keys() == g2.keys()
+    for k in g1:
+        if int(k.split(".")[0]) < n_back:
+            assert g1[k] is not None and g2[k] is not None and torch.equal(g1[k], g2[k]), k
+            assert float(g1[k].abs().max()) > 0, k
+    assert not ops.WeightQuantBatch.pending
+
+
 def test_bad_arguments_raise():
     """Error convention of the boundary: negative rc -> OQError with the library's message; CPU tensors refused."""
     from omniquant_amd import ops, OQError, _capi as C
