@@ -133,12 +133,26 @@ class QuantBlockMixin:
         if os.environ.get("OQ_WQ_ORDER", "1") != "0":
             rank = {nm["o"]: 0, nm["v"]: 1, nm["k"]: 2, nm["q"]: 3}
             order.sort(key=lambda it: rank.get(it[0], -1))
+        fc1_group = [m for m in nm["fc1"] if m in mlp and m in specs]
+        batch_fc1 = len(fc1_group) > 1 and os.environ.get("OQ_WQ_BATCH_MLP", "0") != "0"
         with ops.WeightQuantBatch():        # the weights quantised here and now (q, k, v, o) share one launch per direction
             for mod, sp in order:
                 if mod in mlp:
-                    def make(mod=mod, sp=sp):
-                        w_, ws_ = quant(mod, sp)
-                        mod.temp_weight, mod.temp_bias = w_, mlp_bias(mod, ws_)
+                    if batch_fc1 and mod in fc1_group:
+                        def make(mod=mod):
+                            # whichever of gate / up is needed first quantises both in one launch
+                            res = {}
+                            with ops.WeightQuantBatch():
+                                for m2 in fc1_group:
+                                    res[m2] = quant(m2, specs[m2])
+                            for m2 in fc1_group:
+                                m2.temp_weight, m2.temp_bias = res[m2][0], mlp_bias(m2, res[m2][1])
+                                if m2 is not mod:
+                                    m2.__dict__.pop("_lazy_temp", None)
+                    else:
+                        def make(mod=mod, sp=sp):
+                            w_, ws_ = quant(mod, sp)
+                            mod.temp_weight, mod.temp_bias = w_, mlp_bias(mod, ws_)
                     lazy[mod] = make
                 else:
                     wq[mod], ws[mod] = quant(mod, sp)
