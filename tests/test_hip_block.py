@@ -2,10 +2,12 @@
 HIP path vs the golden vectors generated from the reference (float32 parity mode), plus bf16-mode sanity and the
 hipGraph-replayed step."""
 import glob
+import math
 import os
 
 import numpy as np
 import pytest
+
 import torch
 
 from conftest import GOLDEN, load_golden
@@ -282,6 +284,32 @@ def test_calibration_is_bitwise_reproducible():
         res = calibrate_block(q, args, "llama", 0, x.clone(), x.clone(), None, mask, pos, sc, sh, use_graph=True)
         outs.append(res)
     assert outs[0]["losses"] == outs[1]["losses"]
+    for k_ in outs[0]["omni"]:
+        assert torch.equal(outs[0]["omni"][k_], outs[1]["omni"][k_]), k_
+
+
+def test_multi_matrix_weight_quantiser_leaves_the_calibration_unchanged(monkeypatch):
+    """ops.WeightQuantBatch (q/k/v/o weights in one quantiser launch per direction, backward launches deferred until the
+    last sibling's gradient arrived) against one launch per matrix: bit-identical losses and learned tensors over two
+    epochs of a hidden-2048 block (rows long enough for the row-group LET kernels), hipGraph path."""
+    from omniquant_amd.calibrate import calibrate_block, default_args
+    from omniquant_amd.synthetic import make_config, make_layer, make_calib_inputs, causal_mask, synth_act_stats
+    from omniquant_amd.llama_block import QuantLlamaDecoderLayer
+    H = 2048
+    cfg = make_config(None, family="llama", hidden_size=H, inter=2048, heads=16, kv_heads=16)
+    args = default_args(wbits=4, abits=4, lwc=True, let=True, epochs=2, nsamples=3, net="llama")
+    Tn = 128
+    x = make_calib_inputs(3, Tn, H, dtype=torch.bfloat16).to(DEV)
+    mask = causal_mask(Tn).to(DEV)
+    pos = torch.arange(Tn, device=DEV)[None]
+    sc, sh = synth_act_stats(cfg, 1)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("OQ_WQ_BATCH", flag)
+        q = QuantLlamaDecoderLayer(cfg, make_layer(cfg, seed=7, device=DEV), args).to(DEV)
+        outs.append(calibrate_block(q, args, "llama", 0, x.clone(), x.clone(), None, mask, pos, sc, sh, use_graph=True))
+    assert outs[0]["losses"] == outs[1]["losses"]
+    assert all(math.isfinite(v) for v in outs[0]["losses"])
     for k_ in outs[0]["omni"]:
         assert torch.equal(outs[0]["omni"][k_], outs[1]["omni"][k_]), k_
 
