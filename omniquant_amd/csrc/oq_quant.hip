@@ -7,7 +7,9 @@
 // reductions (+ one LDS exchange across waves for whole-row segments), quantised and written once.  Column-wise LET
 // gradients are accumulated in registers across the rows a workgroup walks (lane -> column mapping is fixed), written
 // as per-workgroup partial rows and finished by colreduce_kernel in a fixed order (no atomics anywhere).
-// By bytes these kernels are HBM-bound; measured, they are bound by VALU issue.
+// By bytes these kernels are HBM-bound; measured, the segment kernels of this file are bound by instruction issue and
+// per-row synchronisation: whole-row segments are served by oq_rowq.hip, these remain for grouped
+// weights and as the OQ_ROWQ=0 reference.
 #include <stdlib.h>
 #include <type_traits>
 #include "oq_common.h"

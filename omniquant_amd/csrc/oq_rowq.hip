@@ -472,7 +472,10 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
 // rows of the workgroup (written once, as one partial row per workgroup, at the end).  What the segment kernels pay per
 // ROW and per WAVE -- the sigmoids, scale / zero-point, the reductions' tail and two barriers -- is paid once per row:
 // wave w finalises row w of the group, the others read the result from LDS; 2 (forward) / 3 (backward) barriers per
-// FOUR rows.  All 4 rows' loads are in flight together (8-16 KB per wave).
+// group.  The forward walks groups of 2 rows when rows are <= 4096 elements (fewer registers, more workgroups); the
+// backward walks groups of 4 with the next row -- and the next group's row constants -- prefetched.  Element loops carry no
+// per-element selects: row_div / row_mul presence is a template parameter (a uniform `if` inside an unrolled loop is
+// compiled to v_cndmask per element), amax / amin ties are found per 8-element chunk with v_max3 / v_min3.
 constexpr int RG = 4;
 #ifndef LETQ_FWD_WPE
 #define LETQ_FWD_WPE 3      // min waves per SIMD the register allocator must leave room for
