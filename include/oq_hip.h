@@ -229,6 +229,12 @@ int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, int dtype, i
 int oq_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);
 int oq_scale(const void* a, float s, void* y, int dtype, int64_t n, void* stream);
 
+/* oq_copy_samples: n (1..3) device-to-device copies of bytes_each bytes (a multiple of 16) in ONE launch: the current
+ * calibration sample and its teacher output(s) -- quant_inps[j], fp_inps[j] (, fp_inps_2[j]) of quantize/omniquant.py:216-219
+ * -- into the fixed buffers the replayed hipGraph of the step reads. */
+int oq_copy_samples(int n, const void* src0, void* dst0, const void* src1, void* dst1, const void* src2, void* dst2,
+                    int64_t bytes_each, void* stream);
+
 /* ---- optimiser (utils.py:11-24,32-46; torch.optim.AdamW at quantize/omniquant.py:207-208;
  *      models/transformation.py:5-20 truncate_number) ----------------------------------------------------
  * Learnables of a block live in ONE flat f32 arena: [0,n_let) LET params (lr_let), [n_let,n) LWC (lr_lwc).

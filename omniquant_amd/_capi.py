@@ -45,6 +45,7 @@ SIGNATURES = {
     "oq_mse_fwd_bwd": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],
     "oq_add": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_scale": [_vp, _f32, _vp, _i32, _i64, _vp],
+    "oq_copy_samples": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_gradnorm": [_vp, _i64, _vp, _vp, _vp],
     "oq_adamw": [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp],
     "oq_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],

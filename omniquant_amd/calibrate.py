@@ -158,10 +158,14 @@ class StepRunner:
 
     def run(self, x, t1, t2=None):
         """x, t1, t2: [bs, T, H] device tensors of this sample.  Returns nothing; loss/norm stay on device."""
-        self.x.copy_(x)
-        self.t1.copy_(t1)
-        if self.t2 is not None:
-            self.t2.copy_(t2)
+        pairs = [(x, self.x), (t1, self.t1)] + ([(t2, self.t2)] if self.t2 is not None else [])
+        if all(s.is_contiguous() and s.dtype == d.dtype and s.shape == d.shape and s.is_cuda for s, d in pairs) \
+                and (self.x.numel() * self.x.element_size()) % 16 == 0:
+            flat = [C.ptr(t) for s, d in pairs for t in (s, d)] + [None] * (6 - 2 * len(pairs))
+            C.call("oq_copy_samples", len(pairs), *flat, self.x.numel() * self.x.element_size(), C.stream())   # one launch
+        else:
+            for s, d in pairs:
+                d.copy_(s)
         if self.use_graph:
             if self.graph is None:
                 self._capture()

@@ -401,6 +401,48 @@ extern "C" int oq_scale(const void* a, float s, void* y, int dtype, int64_t n, v
     EW_FWD("oq_scale", 3, a, a, s);
 }
 
+// ---- the step's input sample(s) -> the static buffers a replayed hipGraph reads: up to three 16-byte-granular copies in
+// ONE launch (quantize/omniquant.py:216-219 indexes the banks in place; a captured graph needs fixed addresses)
+namespace {
+struct Copy3 {
+    const u32x4* src[3];
+    u32x4* dst[3];
+    int64_t nvec;       // 16-byte vectors per pair
+    int n;
+};
+__global__ void __launch_bounds__(256) copy_samples_kernel(Copy3 c) {
+    const u32x4* s = c.src[blockIdx.y];
+    u32x4* d = c.dst[blockIdx.y];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < c.nvec; i += 4 * stride) {          // four independent 16-byte loads in flight per thread
+        const u32x4 a = s[i], b = s[i + stride], e = s[i + 2 * stride], f = s[i + 3 * stride];
+        d[i] = a; d[i + stride] = b; d[i + 2 * stride] = e; d[i + 3 * stride] = f;
+    }
+    for (; i < c.nvec; i += stride) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int oq_copy_samples(int n, const void* src0, void* dst0, const void* src1, void* dst1, const void* src2, void* dst2,
+                               int64_t bytes_each, void* stream) {
+    OQ_CHECK_ARG(n >= 1 && n <= 3 && bytes_each > 0 && bytes_each % 16 == 0, "oq_copy_samples: 1..3 pairs of a multiple of 16 bytes");
+    Copy3 c{};
+    const void* s[3] = {src0, src1, src2};
+    void* d[3] = {dst0, dst1, dst2};
+    for (int i = 0; i < n; ++i) {
+        OQ_CHECK_ARG(s[i] && d[i] && oq_aligned16(s[i]) && oq_aligned16(d[i]), "oq_copy_samples: null or unaligned buffer %d", i);
+        c.src[i] = (const u32x4*)s[i];
+        c.dst[i] = (u32x4*)d[i];
+    }
+    c.nvec = bytes_each / 16;
+    c.n = n;
+    int64_t nb = (c.nvec + 4 * 256 - 1) / (4 * 256);
+    nb = nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
+    hipLaunchKernelGGL(copy_samples_kernel, dim3((unsigned)nb, (unsigned)n), dim3(256), 0, (hipStream_t)stream, c);
+    OQ_CHECK_LAUNCH("oq_copy_samples");
+    return OQ_OK;
+}
+
 extern "C" int oq_silu_mul_bwd(const void* gate, const void* up, const void* gy, void* ggate, void* gup, int dtype,
                                int64_t n, void* stream) {
     EW_CHECK("oq_silu_mul_bwd", n);

@@ -460,6 +460,21 @@ def test_weight_quant_batch_matches_single_launches(n_back, routed):
     assert not ops.WeightQuantBatch.pending
 
 
+def test_copy_samples_one_launch():
+    """oq_copy_samples: the step's input sample and teacher output(s) reach the hipGraph's static buffers in one launch."""
+    from omniquant_amd import _capi as C
+    g = torch.Generator().manual_seed(2)
+    for n, numel, dt in ((2, 2048 * 4096, torch.bfloat16), (3, 8 * 1000, torch.float32), (1, 8, torch.bfloat16)):
+        src = [torch.randn(numel, generator=g).to(dt).to(DEV) for _ in range(n)]
+        dst = [torch.zeros(numel, dtype=dt, device=DEV) for _ in range(n)]
+        flat = [C.ptr(t) for s_, d_ in zip(src, dst) for t in (s_, d_)] + [None] * (6 - 2 * n)
+        C.call("oq_copy_samples", n, *flat, numel * src[0].element_size(), C.stream())
+        for s_, d_ in zip(src, dst):
+            assert torch.equal(s_, d_)
+    with pytest.raises(C.OQError):
+        C.call("oq_copy_samples", 1, C.ptr(src[0]), C.ptr(dst[0]), None, None, None, None, 24, C.stream())
+
+
 def test_bad_arguments_raise():
     """Error convention of the boundary: negative rc -> OQError with the library's message; CPU tensors refused."""
     from omniquant_amd import ops, OQError, _capi as C
