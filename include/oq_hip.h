@@ -175,6 +175,17 @@ int oq_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, int64_t T, int n
                       int nbits, void* y, int y_dtype, float* scale, float* zp, float* xmin, float* xmax, void* stream);
 int oq_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nh, int hd, const float* cos, const float* sin,
                       int nbits, const float* xmin, const float* xmax, const void* g, int g_dtype, void* gx, void* stream);
+
+/* oq_qkv_rope_quant_fwd/bwd: the same for q, k and v in ONE launch per direction.  x (and gx) is the merged projection
+ * output [rows, nhq + nhk + nhv, 128] (the three GEMMs write column blocks of one buffer); q and k heads are rotated, v
+ * heads are not (models/int_llama_layer.py:124-125); the quantised tensors / their gradients stay three contiguous
+ * [rows, nh_i, 128] buffers as the attention kernels expect.  scale / zp / xmin / xmax: [rows * (nhq + nhk + nhv)]. */
+int oq_qkv_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nhq, int nhk, int nhv, int hd,
+                          const float* cos, const float* sin, int nbits, void* yq, void* yk, void* yv, int y_dtype,
+                          float* scale, float* zp, float* xmin, float* xmax, void* stream);
+int oq_qkv_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nhq, int nhk, int nhv, int hd,
+                          const float* cos, const float* sin, int nbits, const float* xmin, const float* xmax,
+                          const void* gq, const void* gk, const void* gv, int g_dtype, void* gx, void* stream);
 /* Fused producer + quantiser for the down_proj input of the LLaMA MLP (models/int_llama_layer.py:44-45 followed by the
  * act_quantizer call of quantize/int_linear.py:59-60): y = per-token fake_quant(silu(gate) * up), rows x cols, cols =
  * 512 .. 32768 (multiple of 8).  The product reaches the quantiser in fp32 and never goes through memory.  The backward

@@ -31,7 +31,23 @@ struct RQ {
     float *scale, *zp, *xmin, *xmax;      // [rows * nh]
     const void* g;
     void* gx;
+    // merged q / k / v call: x (and gx) is [rows, nh, 128] with nh = nh0 + nh1 + nh2 heads; heads [0, nh0) are written to
+    // y (read from g), [nh0, nh0 + nh1) to y1 (g1), the rest to y2 (g2); the first `nrope` heads are rotated
+    void *y1, *y2;
+    const void *g1, *g2;
+    int nh0, nh1, nrope;
 };
+
+struct HeadSel {        // which output / gradient tensor a head belongs to, and its index there
+    int t, hl, nht;
+};
+__device__ __forceinline__ HeadSel head_sel(const RQ& p, int h) {
+    HeadSel o;
+    if (h < p.nh0) { o.t = 0; o.hl = h; o.nht = p.nh0; }
+    else if (h < p.nh0 + p.nh1) { o.t = 1; o.hl = h - p.nh0; o.nht = p.nh1; }
+    else { o.t = 2; o.hl = h - p.nh0 - p.nh1; o.nht = p.nh - p.nh0 - p.nh1; }
+    return o;
+}
 
 constexpr int HD = 128, LPS = 4, NC = 4;      // lanes per segment, chunks of 8 per lane
 
@@ -41,7 +57,7 @@ __device__ __forceinline__ void rotated(const RQ& p, int64_t seg, int l, float (
     const TIN* px = reinterpret_cast<const TIN*>(p.x) + seg * HD;
 #pragma unroll
     for (int c = 0; c < NC; ++c) Vec8<TIN>::load(px + (c * 4 + l) * 8, x[c]);
-    if (p.cs) {
+    if (p.cs && (int)(seg % p.nh) < p.nrope) {
         const int64_t t = (seg / p.nh) % p.T;
         float r[NC][8];
 #pragma unroll
@@ -75,6 +91,8 @@ __global__ void __launch_bounds__(256) ropeq_fwd_kernel(RQ p) {
         if (seg >= nseg) seg = nseg - 1;                // surplus quads redo the last segment (same values stored again)
         float x[NC][8];
         rotated<TIN>(p, seg, l, x);
+        const HeadSel hs = head_sel(p, (int)(seg % p.nh));
+        TOUT* yseg = (hs.t == 0 ? ybase : reinterpret_cast<TOUT*>(hs.t == 1 ? p.y1 : p.y2)) + ((seg / p.nh) * hs.nht + hs.hl) * HD;
         float hi = -INFINITY, lo = INFINITY;
         uint64_t nanm = 0;
 #pragma unroll
@@ -111,7 +129,7 @@ __global__ void __launch_bounds__(256) ropeq_fwd_kernel(RQ p) {
                     yv[i] = (v - q.z) * q.s;
                 }
             }
-            Vec8<TOUT>::store(ybase + seg * HD + (c * 4 + l) * 8, yv);
+            Vec8<TOUT>::store(yseg + (c * 4 + l) * 8, yv);
         }
         if (l == 0) {
             p.scale[seg] = q.s;
@@ -143,10 +161,13 @@ __global__ void __launch_bounds__(256) ropeq_bwd_kernel(RQ p) {
         // all-NaN segment without a per-element select ((r - t) + t == r for every finite t)
         const float zr = q.s == 0.f ? NAN : q.z;
         float gs = 0.f, chi = 0.f, clo = 0.f;
+        const int head = (int)(seg % p.nh);
+        const HeadSel hs = head_sel(p, head);
+        const TG* gseg = (hs.t == 0 ? gbase : reinterpret_cast<const TG*>(hs.t == 1 ? p.g1 : p.g2)) + ((seg / p.nh) * hs.nht + hs.hl) * HD;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             float G[8];
-            Vec8<TG>::load(gbase + seg * HD + (c * 4 + l) * 8, G);
+            Vec8<TG>::load(gseg + (c * 4 + l) * 8, G);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float tq = x[c][i] * inv_s;
@@ -170,7 +191,7 @@ __global__ void __launch_bounds__(256) ropeq_bwd_kernel(RQ p) {
                 if (x[c][i] == hi) gin[c][i] += tie_hi;
                 if (x[c][i] == lo) gin[c][i] += tie_lo;
             }
-        if (p.cs) {
+        if (p.cs && head < p.nrope) {
             // transposed rotation: gx_e = g_e cos_e - sgn_e * g_partner * sin_e   (cos / sin are equal on both halves)
             const int64_t t = (seg / p.nh) % p.T;
 #pragma unroll
@@ -223,6 +244,7 @@ extern "C" int oq_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, int64
     p.x = x; p.y = y; p.cs = cos; p.sn = sin; p.rows = rows; p.T = T; p.nh = nh; p.nbits = nbits;
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax;
+    p.nh0 = nh; p.nh1 = 0; p.nrope = cos ? nh : 0;
     const dim3 grid(rq_grid(rows * nh)), blk(256);
     hipStream_t st = (hipStream_t)stream;
     switch (x_dtype * 3 + y_dtype) {
@@ -248,6 +270,7 @@ extern "C" int oq_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64
     p.x = x; p.cs = cos; p.sn = sin; p.rows = rows; p.T = T; p.nh = nh; p.nbits = nbits;
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax); p.g = g; p.gx = gx;
+    p.nh0 = nh; p.nh1 = 0; p.nrope = cos ? nh : 0;
     const dim3 grid(rq_grid(rows * nh)), blk(256);
     hipStream_t st = (hipStream_t)stream;
     switch (x_dtype * 3 + g_dtype) {
@@ -259,5 +282,64 @@ extern "C" int oq_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64
             return OQ_E_UNSUPPORTED;
     }
     OQ_CHECK_LAUNCH("oq_rope_quant_bwd");
+    return OQ_OK;
+}
+
+// ---- q, k and v in one launch per direction (same arithmetic as three oq_rope_quant_* calls: q and k rotated, v not) ------
+extern "C" int oq_qkv_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nhq, int nhk, int nhv, int hd,
+                                     const float* cos, const float* sin, int nbits, void* yq, void* yk, void* yv, int y_dtype,
+                                     float* scale, float* zp, float* xmin, float* xmax, void* stream) {
+    OQ_CHECK_ARG(nhq > 0 && nhk > 0 && nhv > 0, "oq_qkv_rope_quant_fwd: head counts %d / %d / %d", nhq, nhk, nhv);
+    const int nh = nhq + nhk + nhv;
+    const int rc = check("oq_qkv_rope_quant_fwd", rows, T, nh, hd, nbits, cos, sin);
+    if (rc) return rc;
+    OQ_CHECK_ARG(x && yq && yk && yv && scale && zp && xmin && xmax && cos && sin, "oq_qkv_rope_quant_fwd: null pointer");
+    OQ_CHECK_ARG(oq_aligned16(x) && oq_aligned16(yq) && oq_aligned16(yk) && oq_aligned16(yv) && oq_aligned16(cos) && oq_aligned16(sin),
+                 "oq_qkv_rope_quant_fwd: 16-byte alignment");
+    RQ p{};
+    p.x = x; p.y = yq; p.y1 = yk; p.y2 = yv; p.cs = cos; p.sn = sin; p.rows = rows; p.T = T; p.nh = nh; p.nbits = nbits;
+    p.inv_q = 1.0f / (float)((1 << nbits) - 1);
+    p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax;
+    p.nh0 = nhq; p.nh1 = nhk; p.nrope = nhq + nhk;
+    const dim3 grid(rq_grid(rows * nh)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dtype * 3 + y_dtype) {
+        case OQ_BF16 * 3 + OQ_BF16: hipLaunchKernelGGL((ropeq_fwd_kernel<bf16_t, bf16_t>), grid, blk, 0, st, p); break;
+        case OQ_F32 * 3 + OQ_BF16: hipLaunchKernelGGL((ropeq_fwd_kernel<float, bf16_t>), grid, blk, 0, st, p); break;
+        case OQ_F32 * 3 + OQ_F32: hipLaunchKernelGGL((ropeq_fwd_kernel<float, float>), grid, blk, 0, st, p); break;
+        default:
+            oq_set_error("oq_qkv_rope_quant_fwd: unsupported dtype pair in=%d out=%d", x_dtype, y_dtype);
+            return OQ_E_UNSUPPORTED;
+    }
+    OQ_CHECK_LAUNCH("oq_qkv_rope_quant_fwd");
+    return OQ_OK;
+}
+
+extern "C" int oq_qkv_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nhq, int nhk, int nhv, int hd,
+                                     const float* cos, const float* sin, int nbits, const float* xmin, const float* xmax,
+                                     const void* gq, const void* gk, const void* gv, int g_dtype, void* gx, void* stream) {
+    OQ_CHECK_ARG(nhq > 0 && nhk > 0 && nhv > 0, "oq_qkv_rope_quant_bwd: head counts %d / %d / %d", nhq, nhk, nhv);
+    const int nh = nhq + nhk + nhv;
+    const int rc = check("oq_qkv_rope_quant_bwd", rows, T, nh, hd, nbits, cos, sin);
+    if (rc) return rc;
+    OQ_CHECK_ARG(x && gq && gk && gv && gx && xmin && xmax && cos && sin, "oq_qkv_rope_quant_bwd: null pointer");
+    OQ_CHECK_ARG(oq_aligned16(x) && oq_aligned16(gq) && oq_aligned16(gk) && oq_aligned16(gv) && oq_aligned16(gx),
+                 "oq_qkv_rope_quant_bwd: 16-byte alignment");
+    RQ p{};
+    p.x = x; p.cs = cos; p.sn = sin; p.rows = rows; p.T = T; p.nh = nh; p.nbits = nbits;
+    p.inv_q = 1.0f / (float)((1 << nbits) - 1);
+    p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax); p.g = gq; p.g1 = gk; p.g2 = gv; p.gx = gx;
+    p.nh0 = nhq; p.nh1 = nhk; p.nrope = nhq + nhk;
+    const dim3 grid(rq_grid(rows * nh)), blk(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (x_dtype * 3 + g_dtype) {
+        case OQ_BF16 * 3 + OQ_BF16: hipLaunchKernelGGL((ropeq_bwd_kernel<bf16_t, bf16_t>), grid, blk, 0, st, p); break;
+        case OQ_F32 * 3 + OQ_BF16: hipLaunchKernelGGL((ropeq_bwd_kernel<float, bf16_t>), grid, blk, 0, st, p); break;
+        case OQ_F32 * 3 + OQ_F32: hipLaunchKernelGGL((ropeq_bwd_kernel<float, float>), grid, blk, 0, st, p); break;
+        default:
+            oq_set_error("oq_qkv_rope_quant_bwd: unsupported dtype pair x=%d g=%d", x_dtype, g_dtype);
+            return OQ_E_UNSUPPORTED;
+    }
+    OQ_CHECK_LAUNCH("oq_qkv_rope_quant_bwd");
     return OQ_OK;
 }

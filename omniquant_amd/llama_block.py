@@ -5,6 +5,7 @@ Data layout: projections produce [bs, T, heads*hd]; q/k/v stay in that head-inte
 transposes).  GQA (num_key_value_heads < num_attention_heads) is handled by the GEMM's zero batch stride.
 """
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -126,16 +127,29 @@ class QuantLlamaAttention(nn.Module):
         fused_qkv = self._fused_rope_quant(hq)
         if fused_qkv:
             # projection -> RoPE -> head-wise fake quant as one node per tensor: the projection output stays fp32 inside it
-            outs = []
-            for lin, qz, rot in ((self.q_proj, self.qkt_matmul.x1_quantizer, True), (self.k_proj, self.qkt_matmul.x2_quantizer, True),
-                                 (self.v_proj, self.pv_matmul.x2_quantizer, False)):
+            trio = ((self.q_proj, self.qkt_matmul.x1_quantizer, True), (self.k_proj, self.qkt_matmul.x2_quantizer, True),
+                    (self.v_proj, self.pv_matmul.x2_quantizer, False))
+            wbs = []
+            for lin, _, _ in trio:
                 w, b = lin._resolve(hq.dtype)
                 if w.dtype != hq.dtype:
                     w = ops.cast(w, hq.dtype)
-                stash = {}
-                outs.append(ops.LinearRopeQuantFn.apply(hq, w, b, cos if rot else None, sin if rot else None, qz.n_bits, hd, stash, sib))
-                qz.scale, qz.round_zero_point = stash["scale"], stash["zp"]
-            q, k, v = outs
+                wbs.append((w, b))
+            same_bits = len({qz.n_bits for _, qz, _ in trio}) == 1
+            if same_bits and os.environ.get("OQ_MERGED_QKV", "1") != "0":
+                # one node for the three: RoPE + head quant of all heads in one launch per direction, one bias column sum
+                stashes = [{}, {}, {}]
+                q, k, v = ops.QKVRopeQuantFn.apply(hq, wbs[0][0], wbs[0][1], wbs[1][0], wbs[1][1], wbs[2][0], wbs[2][1], cos, sin,
+                                                   trio[0][1].n_bits, hd, stashes, sib)
+                for (_, qz, _), st in zip(trio, stashes):
+                    qz.scale, qz.round_zero_point = st["scale"], st["zp"]
+            else:
+                outs = []
+                for (lin, qz, rot), (w, b) in zip(trio, wbs):
+                    stash = {}
+                    outs.append(ops.LinearRopeQuantFn.apply(hq, w, b, cos if rot else None, sin if rot else None, qz.n_bits, hd, stash, sib))
+                    qz.scale, qz.round_zero_point = stash["scale"], stash["zp"]
+                q, k, v = outs
         else:
             q, k, v = QuantLinear.forward_siblings([self.q_proj, self.k_proj, self.v_proj], hq, sib)
             q, k, v = q.view(bsz, q_len, nh, hd), k.view(bsz, q_len, nkv, hd), v.view(bsz, q_len, nkv, hd)

@@ -392,6 +392,100 @@ class LinearRopeQuantFn(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, None
 
 
+class QKVRopeQuantFn(torch.autograd.Function):
+    """q, k, v = LinearRopeQuantFn three times, as ONE autograd node: the three projections write column blocks of one
+    [rows, Nq + Nk + Nv] buffer, RoPE + head-wise fake quant of all heads is one launch per direction
+    (oq_qkv_rope_quant_*), the bias gradients one column sum; the GEMMs stay one per matrix (their weights are separate
+    tensors).  Same arithmetic per element, so results are bit-identical to the three separate nodes.
+    x [bs, T, K]; returns q [bs, T, nhq, hd], k, v [bs, T, nhk|nhv, hd]."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, cos, sin, nbits, hd, stashes, sib=None):
+        ctx.sib = sib
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        ws = [w.contiguous() for w in (wq, wk, wv)]
+        bs_ = [bq, bk, bv]
+        rows, K = x2.shape
+        Ns = [w.shape[0] for w in ws]
+        Ntot = sum(Ns)
+        for w in ws:
+            if w.dtype != x2.dtype:
+                raise C.OQError(f"QKVRopeQuantFn: weight dtype {w.dtype} != activation dtype {x2.dtype}")
+        pre = torch.empty((rows, Ntot), dtype=x2.dtype, device=x2.device)
+        off = 0
+        offs = []
+        for w, b, N in zip(ws, bs_, Ns):
+            gemm(x2, w, pre, rows, N, K, K, K, Ntot, True, True, bias=_f32(b), c_off=off)
+            offs.append(off)
+            off += N
+        nhs = [N // hd for N in Ns]
+        nht = sum(nhs)
+        ys = [torch.empty((rows, N), dtype=x2.dtype, device=x2.device) for N in Ns]
+        scale, zp, xmin, xmax = (torch.empty((rows * nht, 1), dtype=torch.float32, device=x2.device) for _ in range(4))
+        T = x.shape[-2]
+        C.call("oq_qkv_rope_quant_fwd", C.ptr(pre), C.dt(pre), rows, T, nhs[0], nhs[1], nhs[2], hd, C.fptr(cos), C.fptr(sin),
+               int(nbits), C.ptr(ys[0]), C.ptr(ys[1]), C.ptr(ys[2]), C.dt(ys[0]), C.fptr(scale), C.fptr(zp), C.fptr(xmin),
+               C.fptr(xmax), C.stream())
+        if stashes is not None:
+            h0 = 0
+            sv, zv = scale.view(rows, nht, 1), zp.view(rows, nht, 1)
+            for st, n in zip(stashes, nhs):
+                st["scale"], st["zp"] = sv[:, h0:h0 + n], zv[:, h0:h0 + n]       # views of the merged per-(token, head) vectors
+                h0 += n
+        ctx.save_for_backward(x2, *ws, pre, xmin, xmax, cos, sin)
+        ctx.cfg = (T, tuple(nhs), hd, int(nbits), tuple(b is not None for b in bs_), x.shape, tuple(offs))
+        return tuple(y.view(*x.shape[:-1], n, hd) for y, n in zip(ys, nhs))
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        x2, wq, wk, wv, pre, xmin, xmax, cos, sin = ctx.saved_tensors
+        T, nhs, hd, nbits, has_bias, xshape, offs = ctx.cfg
+        rows, K = x2.shape
+        ws = (wq, wk, wv)
+        Ns = [w.shape[0] for w in ws]
+        Ntot = sum(Ns)
+        gs = []
+        for g, N in zip((gq, gk, gv), Ns):
+            if g is None:
+                g = torch.zeros((rows, N), dtype=x2.dtype, device=x2.device)
+            g = g.contiguous()
+            gs.append(g if g.dtype == x2.dtype else g.to(x2.dtype))
+        gpre = torch.empty((rows, Ntot), dtype=x2.dtype, device=x2.device)
+        C.call("oq_qkv_rope_quant_bwd", C.ptr(pre), C.dt(pre), rows, T, nhs[0], nhs[1], nhs[2], hd, C.fptr(cos), C.fptr(sin),
+               nbits, C.fptr(xmin), C.fptr(xmax), C.ptr(gs[0]), C.ptr(gs[1]), C.ptr(gs[2]), C.dt(gs[0]), C.ptr(gpre), C.stream())
+        need = ctx.needs_input_grad         # x, wq, bq, wk, bk, wv, bv, ...
+        gx = None
+        if need[0]:
+            if ctx.sib is not None:
+                # one dL/dx per projection: the first goes back to autograd, the others are summed inside oq_norm_quant_bwd
+                for w, N, off in zip(ws, Ns, offs):
+                    gxi = torch.empty((rows, K), dtype=x2.dtype, device=x2.device)
+                    gemm(gpre, w, gxi, rows, K, N, Ntot, K, K, True, False, a_off=off)
+                    r = ctx.sib.offer(gxi.view(xshape))
+                    if r is not None:
+                        gx = r
+            else:
+                gx2 = torch.empty((rows, K), dtype=x2.dtype, device=x2.device)
+                for i, (w, N, off) in enumerate(zip(ws, Ns, offs)):
+                    gemm(gpre, w, gx2, rows, K, N, Ntot, K, K, True, False, a_off=off, addend=None if i == 0 else gx2)
+                gx = gx2.view(xshape)
+        gws = [None, None, None]
+        for i, (w, N, off) in enumerate(zip(ws, Ns, offs)):
+            if need[1 + 2 * i]:
+                gws[i] = torch.empty((N, K), dtype=w.dtype, device=x2.device)
+                gemm(gpre, x2, gws[i], N, K, rows, Ntot, K, K, False, False, a_off=off)
+        gbs = [None, None, None]
+        if any(has_bias[i] and need[2 + 2 * i] for i in range(3)):
+            gb = torch.empty((Ntot,), dtype=torch.float32, device=x2.device)
+            ws_n = C.size_call("oq_colsum_workspace", rows, Ntot)
+            wsb = torch.empty(ws_n, dtype=torch.float32, device=x2.device)
+            C.call("oq_colsum", C.ptr(gpre), C.dt(gpre), rows, Ntot, C.fptr(gb), C.fptr(wsb), ws_n, C.stream())
+            for i, (N, off) in enumerate(zip(Ns, offs)):
+                if has_bias[i] and need[2 + 2 * i]:
+                    gbs[i] = gb[off:off + N]
+        return (gx, gws[0], gbs[0], gws[1], gbs[1], gws[2], gbs[2], None, None, None, None, None, None)
+
+
 class SiblingLinearFn(torch.autograd.Function):
     """Projections that read the SAME input (q/k/v; gate/up): y_i = x @ w_i.T + b_i.  One autograd node, so the
     input gradient dX = sum_i dY_i @ W_i is ACCUMULATED by the dgrad GEMMs' epilogue (addend = the running sum) instead

@@ -475,6 +475,55 @@ def test_copy_samples_one_launch():
         C.call("oq_copy_samples", 1, C.ptr(src[0]), C.ptr(dst[0]), None, None, None, None, 24, C.stream())
 
 
+@pytest.mark.parametrize("heads", [(4, 4, 4), (8, 2, 2)])
+@pytest.mark.parametrize("use_sib", [False, True])
+def test_merged_qkv_rope_quant_matches_three_nodes(heads, use_sib):
+    """ops.QKVRopeQuantFn (q, k, v projections into one buffer, RoPE + head-wise quant of all heads in one launch per
+    direction, one bias column sum) against three ops.LinearRopeQuantFn nodes: bit-identical outputs, weight / bias
+    gradients and input-gradient pieces; also with grouped-query head counts."""
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(21)
+    bs, T, K, hd = 1, 64, 512, 128
+    nhq, nhk, nhv = heads
+    x = torch.randn(bs, T, K, generator=g).bfloat16().to(DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.outer(torch.arange(T).float(), inv)
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(DEV).contiguous(), emb.sin().to(DEV).contiguous()
+    Ws = [(torch.randn(n * hd, K, generator=g) * 0.05).bfloat16().to(DEV) for n in heads]
+    Bs = [torch.randn(n * hd, generator=g).to(DEV) for n in heads]
+    Gs = [torch.randn(bs, T, n, hd, generator=g).bfloat16().to(DEV) for n in heads]
+
+    def run(merged):
+        xl = x.clone().requires_grad_(True)
+        ws = [w.clone().requires_grad_(True) for w in Ws]
+        bb = [b.clone().requires_grad_(True) for b in Bs]
+        sib = ops.SiblingGrads() if use_sib else None
+        if merged:
+            outs = ops.QKVRopeQuantFn.apply(xl, ws[0], bb[0], ws[1], bb[1], ws[2], bb[2], cos, sin, 4, hd, [{}, {}, {}], sib)
+        else:
+            outs = [ops.LinearRopeQuantFn.apply(xl, ws[i], bb[i], cos if i < 2 else None, sin if i < 2 else None, 4, hd, {}, sib)
+                    for i in range(3)]
+        loss = sum((o.float() * G.float()).sum() for o, G in zip(outs, Gs))
+        loss.backward()
+        torch.cuda.synchronize()
+        gx = xl.grad.float().clone()
+        if sib is not None:
+            for part in sib.take():
+                gx = gx + part.float()
+        return [o.detach().clone() for o in outs], [w.grad.clone() for w in ws], [b.grad.clone() for b in bb], gx
+
+    o1, w1, b1, x1 = run(False)
+    o2, w2, b2, x2 = run(True)
+    for a, b in zip(o1 + w1 + b1, o2 + w2 + b2):
+        assert a.shape == b.shape and torch.equal(a, b)
+    if use_sib:
+        assert torch.equal(x1, x2)      # the same three pieces, added in the same order here
+    else:
+        # separate nodes: autograd adds three bf16 tensors; merged: the dgrad GEMMs accumulate in their epilogue
+        assert float((x1 - x2).abs().max()) <= 2e-2 * float(x1.abs().max())
+
+
 def test_bad_arguments_raise():
     """Error convention of the boundary: negative rc -> OQError with the library's message; CPU tensors refused."""
     from omniquant_amd import ops, OQError, _capi as C
