@@ -147,6 +147,11 @@ int oq_rope(const void* x, void* y, int dtype, int64_t T, int64_t heads, int64_t
 int oq_silu_mul_fwd(const void* gate, const void* up, void* y, int dtype, int64_t n, void* stream);
 int oq_silu_mul_bwd(const void* gate, const void* up, const void* gy, void* ggate, void* gup, int dtype, int64_t n,
                     void* stream);
+/* The same two on [rows, cols] problems whose gate / up (and ggate / gup) rows are `ld` elements apart (column blocks of a
+ * stacked gate/up GEMM's buffer); y / gy dense.  cols and ld multiples of 8. */
+int oq_silu_mul_fwd_2d(const void* gate, const void* up, void* y, int dtype, int64_t rows, int64_t cols, int64_t ld, void* stream);
+int oq_silu_mul_bwd_2d(const void* gate, const void* up, const void* gy, void* ggate, void* gup, int dtype, int64_t rows,
+                       int64_t cols, int64_t ld, void* stream);
 /* norm -> per-token fake quant in one kernel per direction: y = fake_quant(norm(x)) with OmniLlamaRMSNorm (is_layernorm 0) or
  * OmniLayerNorm (1) semantics (quantize/omni_norm.py:26-34,52-63) and the dynamic per-token asymmetric quantiser of the
  * QuantLinear behind it (quantize/int_linear.py:59-60, quantize/quantizer.py:84-147).  rows x cols, cols = 512 .. 8192
@@ -190,11 +195,14 @@ int oq_qkv_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64_t T, i
  * act_quantizer call of quantize/int_linear.py:59-60): y = per-token fake_quant(silu(gate) * up), rows x cols, cols =
  * 512 .. 32768 (multiple of 8).  The product reaches the quantiser in fp32 and never goes through memory.  The backward
  * takes g = dL/dy and the forward's xmin / xmax and writes dL/dgate, dL/dup (straight-through rounding, clip mask and the
- * amax / amin tie terms of quantize/quantizer.py:122-147 included).  dtype OQ_BF16 or OQ_F32 (all tensors alike). */
-int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype, int64_t rows, int64_t cols, int nbits, void* y,
+ * amax / amin tie terms of quantize/quantizer.py:122-147 included).  dtype OQ_BF16 or OQ_F32 (all tensors alike).
+ * ld: row stride (elements, multiple of 8, >= cols; 0 = cols) of gate / up and of ggate / gup -- gate | up may be the two
+ * column blocks of the ONE buffer a stacked gate/up GEMM writes, and their gradients the column blocks of the buffer the
+ * stacked dgrad / wgrad GEMMs read; y and g are always dense [rows, cols]. */
+int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype, int64_t rows, int64_t cols, int64_t ld, int nbits, void* y,
                           float* scale, float* zp, float* xmin, float* xmax, void* stream);
-int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int64_t rows, int64_t cols, int nbits,
-                          const float* xmin, const float* xmax, void* ggate, void* gup, void* stream);
+int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int64_t rows, int64_t cols, int64_t ld,
+                          int nbits, const float* xmin, const float* xmax, void* ggate, void* gup, void* stream);
 int oq_relu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream);
 int oq_relu_bwd(const void* x, const void* gy, void* gx, int dtype, int64_t n, void* stream);
 int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols, float alpha, const float* mask,

@@ -30,14 +30,16 @@ SIGNATURES = {
     "oq_rope": [_vp, _vp, _i32, _i64, _i64, _i64, _vp, _vp, _i32, _vp],
     "oq_silu_mul_fwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_silu_mul_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
+    "oq_silu_mul_fwd_2d": [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp],
+    "oq_silu_mul_bwd_2d": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp],
     "oq_norm_quant_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "oq_norm_quant_bwd": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_rope_quant_fwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_rope_quant_bwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "oq_qkv_rope_quant_fwd": [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_qkv_rope_quant_bwd": [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
-    "oq_silu_mul_quant_fwd": [_vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "oq_silu_mul_quant_bwd": [_vp, _vp, _vp, _i32, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    "oq_silu_mul_quant_fwd": [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+    "oq_silu_mul_quant_bwd": [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_relu_fwd": [_vp, _vp, _i32, _i64, _vp],
     "oq_relu_bwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_softmax_fwd": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _i64, _i32, _vp],

@@ -95,7 +95,31 @@ class QuantBlockMixin:
         else:
             mod._temp_ready = None
 
-    def _let_temporaries(self, out_dtype, lazy_mlp=False):
+    def _weight_slabs(self, nm, dtype):
+        """{module: destination of its fake-quant weight}: q | k | v (and gate | up) are written back to back into one
+        buffer each, so that the sibling projections run as ONE GEMM per direction (ops.stacked_rows).  Per step, from the
+        caching allocator (inside the captured graph's pool the addresses are static)."""
+        dest = {}
+        if os.environ.get("OQ_STACKED_GEMM", "1") == "0":
+            return dest
+        for group in ([nm["q"], nm["k"], nm["v"]], list(nm["fc1"])):
+            # (the reference lists fc1 as [up_proj, gate_proj]; the MLP consumes gate first)
+            if group and len(group) > 1 and all(isinstance(m, QuantLinear) for m in group) and \
+                    len({(m.in_features, m.weight.device) for m in group}) == 1 and \
+                    not any(m.weight_quantizer._identity() for m in group):
+                if group[0] is not nm["q"]:
+                    group = sorted(group, key=lambda m: 0 if m is getattr(getattr(self, "mlp", None), "gate_proj", None) else 1)
+                dev = group[0].weight.device
+                slab = torch.empty((sum(m.out_features for m in group), group[0].in_features), dtype=dtype, device=dev)
+                # the LET by-product w @ shift of gate / up IS their bias (no vector kernel in between): stacked as well
+                ws = torch.empty((slab.shape[0],), dtype=torch.float32, device=dev) if group[0] is not nm["q"] else None
+                r = 0
+                for m in group:
+                    dest[m] = slab[r:r + m.out_features] if ws is None else (slab[r:r + m.out_features], ws[r:r + m.out_features])
+                    r += m.out_features
+        return dest
+
+    def _let_temporaries(self, out_dtype, lazy_mlp=False, stack=False):
         """Fused LET path: 6 fused transform+fake-quant kernels (one per smoothed linear) + ONE vector kernel for
         every norm weight/bias and projection bias.  Returns {module: (temp_weight, temp_bias)} and the norm temps.
         lazy_mlp: the MLP weights (no coupling with the vector kernel) are NOT quantised here; instead
@@ -115,12 +139,13 @@ class QuantBlockMixin:
         f = self._f32c
         mlp = set(nm["fc1"]) | {nm["last"]} if lazy_mlp else set()
         wq, ws, lazy = {}, {}, {}
+        dest = self._weight_slabs(nm, out_dtype) if stack else {}
 
         def quant(mod, sp):
             if sp.shift is not None:
                 return mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype, col_mul=sp.col_mul,
-                                                     row_div=sp.row_div, row_mul=sp.row_mul, shift=sp.shift)
-            return mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype), None
+                                                     row_div=sp.row_div, row_mul=sp.row_mul, shift=sp.shift, out=dest.get(mod))
+            return mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype, out=dest.get(mod)), None
 
         def mlp_bias(mod, wsh):
             if mod is nm["last"]:
@@ -182,7 +207,7 @@ class QuantBlockMixin:
                 side.wait_stream(main)      # parameters were updated (AdamW / truncate) on the main stream
             lazy_mlp = bool(self.__dict__.get("_lazy_mlp_quant")) and not forked
             with torch.cuda.stream(side):
-                wq, bias, t1, t2 = self._let_temporaries(dt, lazy_mlp)
+                wq, bias, t1, t2 = self._let_temporaries(dt, lazy_mlp, stack=True)
                 for mod in wq:
                     self._publish(mod, wq[mod], bias[mod], side, forked)
                 for mod, fn in self.__dict__.pop("_lazy_let", {}).items():
@@ -201,6 +226,7 @@ class QuantBlockMixin:
                 side.wait_stream(main)
             lazy_mlp = bool(self.__dict__.get("_lazy_mlp_quant")) and not forked
             mlp = set(nm["fc1"]) | {nm["last"]} if lazy_mlp else set()
+            dest = self._weight_slabs(nm, dt)
             with torch.cuda.stream(side):
                 mods = list(self._quant_linears())
                 if os.environ.get("OQ_WQ_ORDER", "1") != "0":       # last-used-first, see _let_temporaries
@@ -209,13 +235,15 @@ class QuantBlockMixin:
                 for mod in mods:
                     if mod in mlp:
                         def make(mod=mod):
-                            mod.temp_weight, mod.temp_bias = mod.weight_quantizer.quantize(mod.weight, out_dtype=dt), mod.bias
+                            mod.temp_weight, mod.temp_bias = mod.weight_quantizer.quantize(mod.weight, out_dtype=dt,
+                                                                                           out=dest.get(mod)), mod.bias
                         mod.temp_weight, mod.temp_bias = None, None
                         mod.use_temporary_parameter = True
                         mod._temp_ready = None
                         mod.__dict__["_lazy_temp"] = make
                     else:
-                        self._publish(mod, mod.weight_quantizer.quantize(mod.weight, out_dtype=dt), mod.bias, side, forked)
+                        self._publish(mod, mod.weight_quantizer.quantize(mod.weight, out_dtype=dt, out=dest.get(mod)), mod.bias,
+                                      side, forked)
 
     def clear_temp_variable(self):
         nm = self._let_names()

@@ -89,6 +89,43 @@ __global__ void silu_mul_bwd_kernel(const T* gate, const T* up, const T* gy, T* 
     }
 }
 
+// silu(gate) * up and its backward on [rows, cols] problems whose gate / up (ggate / gup) rows lie `ld` elements apart: the two
+// column blocks of the buffer a stacked gate/up GEMM writes (resp. the stacked dgrad / wgrad GEMMs read); y / gy are dense.
+template <typename T>
+__global__ void silu_mul_fwd_2d_kernel(const T* gate, const T* up, T* y, int64_t rows, int64_t cols, int64_t ld) {
+    const int64_t cv = cols / 8, nvec = rows * cv;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = v / cv, c = (v - r * cv) * 8;
+        float x[8], u[8], o[8];
+        Vec8<T>::load(gate + r * ld + c, x);
+        Vec8<T>::load(up + r * ld + c, u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = (x[i] / (1.f + expf(-x[i]))) * u[i];
+        Vec8<T>::store(y + r * cols + c, o);
+    }
+}
+
+template <typename T>
+__global__ void silu_mul_bwd_2d_kernel(const T* gate, const T* up, const T* gy, T* gg, T* gu, int64_t rows, int64_t cols, int64_t ld) {
+    const int64_t cv = cols / 8, nvec = rows * cv;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = v / cv, c = (v - r * cv) * 8;
+        float x[8], u[8], g[8], og[8], ou[8];
+        Vec8<T>::load(gate + r * ld + c, x);
+        Vec8<T>::load(up + r * ld + c, u);
+        Vec8<T>::load(gy + r * cols + c, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float sg = 1.f / (1.f + expf(-x[i]));
+            const float silu = x[i] * sg;
+            ou[i] = g[i] * silu;
+            og[i] = g[i] * u[i] * (sg * (1.f + x[i] * (1.f - sg)));
+        }
+        Vec8<T>::store(gg + r * ld + c, og);
+        Vec8<T>::store(gu + r * ld + c, ou);
+    }
+}
+
 template <typename T>
 __global__ void relu_bwd_kernel(const T* x, const T* gy, T* gx, int64_t n) {
     const int64_t nvec = n / 8;
@@ -450,6 +487,33 @@ extern "C" int oq_silu_mul_bwd(const void* gate, const void* up, const void* gy,
     DT_SWITCH("oq_silu_mul_bwd", dtype,
               hipLaunchKernelGGL((silu_mul_bwd_kernel<float>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const float*)gate, (const float*)up, (const float*)gy, (float*)ggate, (float*)gup, n),
               hipLaunchKernelGGL((silu_mul_bwd_kernel<bf16_t>), dim3(ew_grid(n / 8)), dim3(256), 0, st, (const bf16_t*)gate, (const bf16_t*)up, (const bf16_t*)gy, (bf16_t*)ggate, (bf16_t*)gup, n));
+}
+
+extern "C" int oq_silu_mul_fwd_2d(const void* gate, const void* up, void* y, int dtype, int64_t rows, int64_t cols, int64_t ld,
+                                  void* stream) {
+    OQ_CHECK_ARG(gate && up && y, "oq_silu_mul_fwd_2d: null pointer");
+    OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && ld >= cols && ld % 8 == 0,
+                 "oq_silu_mul_fwd_2d: rows %lld, cols %lld, ld %lld (multiples of 8, ld >= cols)", (long long)rows, (long long)cols, (long long)ld);
+    OQ_CHECK_ARG(oq_aligned16(gate) && oq_aligned16(up) && oq_aligned16(y), "oq_silu_mul_fwd_2d: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nv = rows * cols / 8;
+    DT_SWITCH("oq_silu_mul_fwd_2d", dtype,
+              hipLaunchKernelGGL((silu_mul_fwd_2d_kernel<float>), dim3(ew_grid(nv)), dim3(256), 0, st, (const float*)gate, (const float*)up, (float*)y, rows, cols, ld),
+              hipLaunchKernelGGL((silu_mul_fwd_2d_kernel<bf16_t>), dim3(ew_grid(nv)), dim3(256), 0, st, (const bf16_t*)gate, (const bf16_t*)up, (bf16_t*)y, rows, cols, ld));
+}
+
+extern "C" int oq_silu_mul_bwd_2d(const void* gate, const void* up, const void* gy, void* ggate, void* gup, int dtype,
+                                  int64_t rows, int64_t cols, int64_t ld, void* stream) {
+    OQ_CHECK_ARG(gate && up && gy && ggate && gup, "oq_silu_mul_bwd_2d: null pointer");
+    OQ_CHECK_ARG(rows > 0 && cols > 0 && cols % 8 == 0 && ld >= cols && ld % 8 == 0,
+                 "oq_silu_mul_bwd_2d: rows %lld, cols %lld, ld %lld (multiples of 8, ld >= cols)", (long long)rows, (long long)cols, (long long)ld);
+    OQ_CHECK_ARG(oq_aligned16(gate) && oq_aligned16(up) && oq_aligned16(gy) && oq_aligned16(ggate) && oq_aligned16(gup),
+                 "oq_silu_mul_bwd_2d: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nv = rows * cols / 8;
+    DT_SWITCH("oq_silu_mul_bwd_2d", dtype,
+              hipLaunchKernelGGL((silu_mul_bwd_2d_kernel<float>), dim3(ew_grid(nv)), dim3(256), 0, st, (const float*)gate, (const float*)up, (const float*)gy, (float*)ggate, (float*)gup, rows, cols, ld),
+              hipLaunchKernelGGL((silu_mul_bwd_2d_kernel<bf16_t>), dim3(ew_grid(nv)), dim3(256), 0, st, (const bf16_t*)gate, (const bf16_t*)up, (const bf16_t*)gy, (bf16_t*)ggate, (bf16_t*)gup, rows, cols, ld));
 }
 
 extern "C" int oq_relu_bwd(const void* x, const void* gy, void* gx, int dtype, int64_t n, void* stream) {

@@ -27,6 +27,7 @@ struct FQ {
     // fused producers (oq_rowq.hip): x = silu(w) * w2 feeds the quantiser directly; the backward writes d/dw to gx, d/dw2 to gx2
     const void* w2;
     void* gx2;
+    int64_t ldw;          // row stride (elements) of w / w2 and gx / gx2 in the fused-producer kernels; 0 = cols
 };
 
 namespace {

@@ -79,20 +79,21 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
         cc[j] = (valid[j] ? c : nchunks - 1) * 8;     // surplus lanes redo the last chunk (benign duplicate stores)
     }
     const TIN* wbase = reinterpret_cast<const TIN*>(p.w);
+    const int64_t LW = (PRO == 1 && p.ldw) ? p.ldw : (int64_t)K;      // row stride of w / w2 (gate | up column blocks of one buffer)
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
     const bool lwc = p.up != nullptr;
     int par = 0;
     for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
         int64_t r = r0 + rslot;
         if (r >= p.rows) r = p.rows - 1;              // surplus waves redo the last row: same values stored again
-        const TIN* wrow = wbase + r * K;
+        const TIN* wrow = wbase + r * LW;
         Raw8<TIN> raw[CH];
         Raw8<TIN> raw2[PRO ? CH : 1];
 #pragma unroll
         for (int j = 0; j < CH; ++j)
             if (j < chn) {
                 raw[j].load(wrow + cc[j]);
-                if constexpr (PRO == 1) raw2[j].load(reinterpret_cast<const TIN*>(p.w2) + r * K + cc[j]);
+                if constexpr (PRO == 1) raw2[j].load(reinterpret_cast<const TIN*>(p.w2) + r * LW + cc[j]);
             }
         const float upl = lwc ? p.up[r] : 0.f, lowl = lwc ? p.low[r] : 0.f;
         const float rd = (LET && p.row_div) ? p.row_div[r] : 1.f;
@@ -237,6 +238,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
     TG* gxbase = reinterpret_cast<TG*>(p.gx);
     TG* gx2base = reinterpret_cast<TG*>(p.gx2);
     const TIN* w2base = reinterpret_cast<const TIN*>(p.w2);
+    const int64_t LW = (PRO == 1 && p.ldw) ? p.ldw : (int64_t)K;      // row stride of w / w2 and of gx / gx2
     // PRO = 1: x = silu(w) * w2; dL/dx (gin) becomes dL/dw = gin * w2 * silu'(w) -> gx and dL/dw2 = gin * silu(w) -> gx2
     auto store_grads = [&](int64_t off, const float (&gin)[8], const float (&wv)[8], const float (&uv)[8]) {
         if constexpr (PRO == 1) {
@@ -259,7 +261,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
     for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
         const bool livew = r0 + rslot < p.rows;             // wave-uniform; dead waves only keep the barriers company
         const int64_t r = livew ? r0 + rslot : p.rows - 1;
-        const TIN* wrow = wbase + r * K;
+        const TIN* wrow = wbase + r * LW;
         const TG* grow = gbase + r * K;
         float gs = 0.f, arm = 0.f;
         int whi = 0, wlo = 0;
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
                 if (j < chn) {
                     rw[j].load(wrow + cc[j]);
                     rg[j].load(grow + cc[j]);
-                    if constexpr (PRO == 1) ru[j].load(w2base + r * K + cc[j]);
+                    if constexpr (PRO == 1) ru[j].load(w2base + r * LW + cc[j]);
                 }
             hi = p.xmax[r];
             lo = p.xmin[r];
@@ -355,7 +357,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
                         if (need_cm) slab_add(acc_cm, acc_stride / 2, j * 64 + lane, ccm);
                         if (need_sh) slab_add(acc_sh, acc_stride / 2, j * 64 + lane, csh);
                     }
-                    if (p.gx) store_grads(r * K + cc[j], gin, w, uu);          // tie chunks are rewritten below
+                    if (p.gx) store_grads(r * LW + cc[j], gin, w, uu);         // tie chunks are rewritten below
                 }
             }
         }
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { xs[i] = w[i]; uu[i] = 0.f; }
                     if constexpr (PRO == 1) {
-                        Vec8<TIN>::load(w2base + r * K + cc[j], uu);
+                        Vec8<TIN>::load(w2base + r * LW + cc[j], uu);
 #pragma unroll
                         for (int i = 0; i < 8; ++i) { float sg; xs[i] = silu_f(w[i], &sg) * uu[i]; }
                     }
@@ -435,7 +437,7 @@ __global__ void __launch_bounds__(512) rowq_bwd_kernel(FQ p, int nw, int chn) {
                     if constexpr (LET) {
                         if (need_cm) slab_add(acc_cm, acc_stride / 2, j * 64 + lane, ccm);
                     }
-                    if (p.gx) store_grads(r * K + cc[j], gin, w, uu);
+                    if (p.gx) store_grads(r * LW + cc[j], gin, w, uu);
                 }
             }
         }
@@ -1309,13 +1311,14 @@ static int silu_q_launch(bool fwd, FQ& p, void* stream) {
     return OQ_OK;
 }
 
-extern "C" int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype, int64_t rows, int64_t cols, int nbits,
+extern "C" int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype, int64_t rows, int64_t cols, int64_t ld, int nbits,
                                      void* y, float* scale, float* zp, float* xmin, float* xmax, void* stream) {
     OQ_CHECK_ARG(gate && up && y && scale && zp && xmin && xmax, "oq_silu_mul_quant_fwd: null pointer");
+    OQ_CHECK_ARG(ld == 0 || (ld >= cols && ld % 8 == 0), "oq_silu_mul_quant_fwd: ld %lld (0 or a multiple of 8 >= cols)", (long long)ld);
     OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_silu_mul_quant_fwd: rows %lld, bitwidth %d", (long long)rows, nbits);
     OQ_CHECK_ARG(oq_aligned16(gate) && oq_aligned16(up) && oq_aligned16(y), "oq_silu_mul_quant_fwd: 16-byte alignment");
     FQ p{};
-    p.w = gate; p.w2 = up; p.rows = rows; p.cols = cols; p.seg = cols; p.nbits = nbits;
+    p.w = gate; p.w2 = up; p.rows = rows; p.cols = cols; p.seg = cols; p.nbits = nbits; p.ldw = ld;
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.y = y; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax;
     if (dtype == OQ_BF16) return silu_q_launch<bf16_t>(true, p, stream);
@@ -1325,13 +1328,15 @@ extern "C" int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype
 }
 
 extern "C" int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int64_t rows, int64_t cols,
-                                     int nbits, const float* xmin, const float* xmax, void* ggate, void* gup, void* stream) {
+                                     int64_t ld, int nbits, const float* xmin, const float* xmax, void* ggate, void* gup,
+                                     void* stream) {
     OQ_CHECK_ARG(gate && up && g && ggate && gup && xmin && xmax, "oq_silu_mul_quant_bwd: null pointer");
+    OQ_CHECK_ARG(ld == 0 || (ld >= cols && ld % 8 == 0), "oq_silu_mul_quant_bwd: ld %lld (0 or a multiple of 8 >= cols)", (long long)ld);
     OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_silu_mul_quant_bwd: rows %lld, bitwidth %d", (long long)rows, nbits);
     OQ_CHECK_ARG(oq_aligned16(gate) && oq_aligned16(up) && oq_aligned16(g) && oq_aligned16(ggate) && oq_aligned16(gup),
                  "oq_silu_mul_quant_bwd: 16-byte alignment");
     FQ p{};
-    p.w = gate; p.w2 = up; p.g = g; p.rows = rows; p.cols = cols; p.seg = cols; p.nbits = nbits;
+    p.w = gate; p.w2 = up; p.g = g; p.rows = rows; p.cols = cols; p.seg = cols; p.nbits = nbits; p.ldw = ld;
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax); p.gx = ggate; p.gx2 = gup;
     if (dtype == OQ_BF16) return silu_q_launch<bf16_t>(false, p, stream);

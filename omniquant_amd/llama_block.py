@@ -35,13 +35,28 @@ class QuantLlamaMLP(nn.Module):
             raise NotImplementedError(f"hidden_act {hidden_act}: only SiLU has a HIP kernel")
 
     def forward(self, x, residual=None, input_is_quantized=False, sib=None):
+        from .linear import _hip_linear
         xq = x if input_is_quantized else self.gate_proj.quantize_input(x)   # gate/up share one act-quant pass
-        gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq, sib)
         dq = self.down_proj.act_quantizer
-        if (self.down_proj.use_act_quant and dq is not None and not self.down_proj.disable_input_quant and dq.enable
-                and dq.n_bits < 16 and not dq.symmetric and dq.metric != "fix0to1" and not dq.group_size
-                and dq.dynamic_method == "per_token" and not dq.lwc and self.down_proj.__dict__.get("_stat_sink") is None
-                and ops.silu_mul_quant_supported(gate, dq.n_bits)):
+        fuse_q = (self.down_proj.use_act_quant and dq is not None and not self.down_proj.disable_input_quant and dq.enable
+                  and dq.n_bits < 16 and not dq.symmetric and dq.metric != "fix0to1" and not dq.group_size
+                  and dq.dynamic_method == "per_token" and not dq.lwc and self.down_proj.__dict__.get("_stat_sink") is None)
+        g_, u_ = self.gate_proj, self.up_proj
+        if all(m.use_temporary_parameter and m.fwd_func is _hip_linear and not m.fwd_kwargs
+               and m.__dict__.get("_stat_sink") is None for m in (g_, u_)) and xq.dtype in (torch.bfloat16, torch.float32) \
+                and g_.out_features % 8 == 0:
+            (wg, bg), (wu, bu) = g_._resolve(xq.dtype), u_._resolve(xq.dtype)
+            if wg.dtype == xq.dtype and ops.stacked_rows([wg, wu]) is not None and ops.stacked_vectors([bg, bu]) is not False:
+                # the two fake-quant weights are row blocks of one buffer (block_common._weight_slabs): gate | up as ONE GEMM
+                # per direction, silu*up (-> down_proj input quantiser) reading the column blocks in place
+                nb = dq.n_bits if (fuse_q and ops.silu_mul_quant_supported(xq.new_empty((0, g_.out_features)), dq.n_bits)) else 0
+                stash = {}
+                act = ops.StackedGateUpFn.apply(xq, wg, bg, wu, bu, nb, stash, sib)
+                if nb:
+                    dq.scale, dq.round_zero_point = stash["scale"], stash["zp"]
+                return self.down_proj(act, input_is_quantized=bool(nb), residual=residual)
+        gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq, sib)
+        if fuse_q and ops.silu_mul_quant_supported(gate, dq.n_bits):
             # act_fn(gate) * up and the down_proj input quantiser in ONE kernel: the product is never stored
             stash = {}
             act = ops.SiluMulQuantFn.apply(gate, up, dq.n_bits, stash)

@@ -107,17 +107,30 @@ class FakeQuantFn(torch.autograd.Function):
     non-differentiable side outputs 'scale' and 'zp' ([rows*cols/seg, 1] f32)."""
 
     @staticmethod
-    def forward(ctx, w, col_mul, row_div, row_mul, shift, up, low, nbits, seg, symmetric, out_dtype, stash):
+    def forward(ctx, w, col_mul, row_div, row_mul, shift, up, low, nbits, seg, symmetric, out_dtype, stash, out=None):
         w = w.contiguous()
         cols = w.shape[-1]
         rows = w.numel() // cols
         nseg = rows * ((cols + seg - 1) // seg)          # a ragged last segment is zero-padded inside the kernel
-        y = torch.empty(w.shape, dtype=out_dtype, device=w.device)
+        ws_out = None
+        if isinstance(out, (tuple, list)):
+            out, ws_out = out
+        if out is not None:
+            # caller-provided destination (a row block of a buffer that stacks sibling weights, see stacked_rows)
+            if out.shape != w.shape or out.dtype != out_dtype or out.device != w.device or not out.is_contiguous():
+                raise C.OQError("FakeQuantFn: `out` must be a contiguous tensor of the weight's shape and the output dtype")
+            y = out
+        else:
+            y = torch.empty(w.shape, dtype=out_dtype, device=w.device)
         scale = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
         zp = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
         xmin = torch.empty((nseg,), dtype=torch.float32, device=w.device)     # consumed by the backward kernel
         xmax = torch.empty((nseg,), dtype=torch.float32, device=w.device)
-        wshift = torch.empty((rows,), dtype=torch.float32, device=w.device) if shift is not None else None
+        wshift = None
+        if shift is not None:
+            if ws_out is not None and (ws_out.shape != (rows,) or ws_out.dtype != torch.float32 or not ws_out.is_contiguous()):
+                raise C.OQError("FakeQuantFn: the w @ shift destination must be a contiguous float32 vector of `rows` elements")
+            wshift = ws_out if ws_out is not None else torch.empty((rows,), dtype=torch.float32, device=w.device)
         cm, rd, rm, sh, u, l = (_f32(t) for t in (col_mul, row_div, row_mul, shift, up, low))
         fargs = (C.ptr(w), C.dt(w), rows, cols, seg, nbits, int(symmetric),
                  C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l),
@@ -198,7 +211,7 @@ class FakeQuantFn(torch.autograd.Function):
                 par._oq_collector.add(par, g)
                 outs[i] = None
         g_cm, g_rd, g_rm, g_sh = outs
-        return gx, g_cm, g_rd, g_rm, g_sh, g_up, g_low, None, None, None, None, None
+        return gx, g_cm, g_rd, g_rm, g_sh, g_up, g_low, None, None, None, None, None, None
 
 
 def _gradient_routing_on():
@@ -206,11 +219,11 @@ def _gradient_routing_on():
 
 
 def fake_quant(x, nbits, seg=None, up=None, low=None, symmetric=False, out_dtype=None, stash=None,
-               col_mul=None, row_div=None, row_mul=None, shift=None):
-    """Functional entry: returns y (and wshift when `shift` is given)."""
+               col_mul=None, row_div=None, row_mul=None, shift=None, out=None):
+    """Functional entry: returns y (and wshift when `shift` is given).  out: destination of y (see FakeQuantFn)."""
     seg = seg or x.shape[-1]
     if (seg == x.shape[-1] and seg <= 512 and col_mul is None and row_div is None and row_mul is None
-            and shift is None and up is None):
+            and shift is None and up is None and out is None):
         # short rows (per-head quantisation over head_dim): pack several segments into one kernel row so a
         # workgroup streams 2-8 KB instead of 256 B; segments never straddle rows, results are identical.
         nrows = x.numel() // seg
@@ -222,8 +235,45 @@ def fake_quant(x, nbits, seg=None, up=None, low=None, symmetric=False, out_dtype
                                      nbits, seg, symmetric, out_dtype or x.dtype, stash)
             return y.view(x.shape)
     y, wshift = FakeQuantFn.apply(x, col_mul, row_div, row_mul, shift, up, low, nbits, seg, symmetric,
-                                  out_dtype or x.dtype, stash)
+                                  out_dtype or x.dtype, stash, out)
     return (y, wshift) if shift is not None else y
+
+
+def stacked_rows(ts):
+    """The 2-D tensors `ts` (same row length, dtype) lie back to back in ONE buffer -> that buffer as one [sum rows, cols]
+    tensor, else None.  Sibling projections whose fake-quant weights were written into such a buffer
+    (block_common: q | k | v and gate | up) run as ONE GEMM per direction: y = x @ [W_0; W_1; ..].T gives the outputs as
+    column blocks, dX = dY @ [W_0; W_1; ..] sums the siblings' input gradients inside the GEMM's fp32 accumulators, and
+    dW = dY.T @ x gives the weight gradients as row blocks."""
+    if os.environ.get("OQ_STACKED_GEMM", "1") == "0" or len(ts) < 2:
+        return None
+    t0 = ts[0]
+    if any(t is None or t.dim() != 2 or not t.is_contiguous() or t.dtype != t0.dtype or t.shape[1] != t0.shape[1]
+           or t.device != t0.device for t in ts):
+        return None
+    es = t0.element_size()
+    base = t0.untyped_storage().data_ptr()
+    for a, b in zip(ts, ts[1:]):
+        if b.untyped_storage().data_ptr() != base or a.data_ptr() + a.numel() * es != b.data_ptr():
+            return None
+    rows = sum(t.shape[0] for t in ts)
+    return torch.empty(0, dtype=t0.dtype, device=t0.device).set_(t0.untyped_storage(), t0.storage_offset(),
+                                                                 (rows, t0.shape[1]), (t0.shape[1], 1))
+
+
+def stacked_vectors(vs):
+    """None (all absent) or the 1-D float32 tensors `vs` as one contiguous vector when they lie back to back; False when
+    they cannot be addressed as one."""
+    if all(v is None for v in vs):
+        return None
+    if any(v is None or v.dim() != 1 or v.dtype != torch.float32 or not v.is_contiguous() for v in vs):
+        return False
+    base = vs[0].untyped_storage().data_ptr()
+    for a, b in zip(vs, vs[1:]):
+        if b.untyped_storage().data_ptr() != base or a.data_ptr() + a.numel() * 4 != b.data_ptr():
+            return False
+    n = sum(v.numel() for v in vs)
+    return torch.empty(0, dtype=torch.float32, device=vs[0].device).set_(vs[0].untyped_storage(), vs[0].storage_offset(), (n,), (1,))
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -412,12 +462,16 @@ class QKVRopeQuantFn(torch.autograd.Function):
             if w.dtype != x2.dtype:
                 raise C.OQError(f"QKVRopeQuantFn: weight dtype {w.dtype} != activation dtype {x2.dtype}")
         pre = torch.empty((rows, Ntot), dtype=x2.dtype, device=x2.device)
-        off = 0
-        offs = []
-        for w, b, N in zip(ws, bs_, Ns):
-            gemm(x2, w, pre, rows, N, K, K, K, Ntot, True, True, bias=_f32(b), c_off=off)
-            offs.append(off)
-            off += N
+        offs = [0, Ns[0], Ns[0] + Ns[1]]
+        wall = stacked_rows(ws)
+        ball = stacked_vectors(bs_) if wall is not None else False
+        ctx.stacked = wall is not None and ball is not False
+        if ctx.stacked:
+            # the three fake-quant weights are row blocks of one buffer: ONE GEMM with N = Nq + Nk + Nv
+            gemm(x2, wall, pre, rows, Ntot, K, K, K, Ntot, True, True, bias=ball)
+        else:
+            for w, b, N, off in zip(ws, bs_, Ns, offs):
+                gemm(x2, w, pre, rows, N, K, K, K, Ntot, True, True, bias=_f32(b), c_off=off)
         nhs = [N // hd for N in Ns]
         nht = sum(nhs)
         ys = [torch.empty((rows, N), dtype=x2.dtype, device=x2.device) for N in Ns]
@@ -455,7 +509,15 @@ class QKVRopeQuantFn(torch.autograd.Function):
                nbits, C.fptr(xmin), C.fptr(xmax), C.ptr(gs[0]), C.ptr(gs[1]), C.ptr(gs[2]), C.dt(gs[0]), C.ptr(gpre), C.stream())
         need = ctx.needs_input_grad         # x, wq, bq, wk, bk, wv, bv, ...
         gx = None
-        if need[0]:
+        wall = stacked_rows(ws) if ctx.stacked else None
+        if need[0] and wall is not None:
+            # dX = dPre @ [Wq; Wk; Wv]: the three projections' input gradients are summed in the GEMM's fp32 accumulators
+            gx2 = torch.empty((rows, K), dtype=x2.dtype, device=x2.device)
+            gemm(gpre, wall, gx2, rows, K, Ntot, Ntot, K, K, True, False)
+            gx = gx2.view(xshape)
+            if ctx.sib is not None:
+                gx = ctx.sib.offer(gx)
+        elif need[0]:
             if ctx.sib is not None:
                 # one dL/dx per projection: the first goes back to autograd, the others are summed inside oq_norm_quant_bwd
                 for w, N, off in zip(ws, Ns, offs):
@@ -470,10 +532,16 @@ class QKVRopeQuantFn(torch.autograd.Function):
                     gemm(gpre, w, gx2, rows, K, N, Ntot, K, K, True, False, a_off=off, addend=None if i == 0 else gx2)
                 gx = gx2.view(xshape)
         gws = [None, None, None]
-        for i, (w, N, off) in enumerate(zip(ws, Ns, offs)):
-            if need[1 + 2 * i]:
-                gws[i] = torch.empty((N, K), dtype=w.dtype, device=x2.device)
-                gemm(gpre, x2, gws[i], N, K, rows, Ntot, K, K, False, False, a_off=off)
+        if wall is not None and need[1] and need[3] and need[5]:
+            # dW of the three as row blocks of one buffer: ONE GEMM with M = Nq + Nk + Nv
+            gwall = torch.empty((Ntot, K), dtype=wall.dtype, device=x2.device)
+            gemm(gpre, x2, gwall, Ntot, K, rows, Ntot, K, K, False, False)
+            gws = [gwall[off:off + N] for N, off in zip(Ns, offs)]
+        else:
+            for i, (w, N, off) in enumerate(zip(ws, Ns, offs)):
+                if need[1 + 2 * i]:
+                    gws[i] = torch.empty((N, K), dtype=w.dtype, device=x2.device)
+                    gemm(gpre, x2, gws[i], N, K, rows, Ntot, K, K, False, False, a_off=off)
         gbs = [None, None, None]
         if any(has_bias[i] and need[2 + 2 * i] for i in range(3)):
             gb = torch.empty((Ntot,), dtype=torch.float32, device=x2.device)
@@ -815,6 +883,86 @@ def silu_mul_quant_supported(gate, nbits):
     return gate.is_cuda and gate.dtype in (torch.bfloat16, torch.float32) and 2 <= nbits < 16 and k % 8 == 0 and 512 <= k <= 32768
 
 
+class StackedGateUpFn(torch.autograd.Function):
+    """act = silu(x @ Wg.T + bg) * (x @ Wu.T + bu), optionally followed by the down_proj input quantiser (nbits in 2..15, as
+    SiluMulQuantFn), for gate / up weights that are the two row blocks of ONE buffer (stacked_rows): the projections are one
+    GEMM with N = 2*I whose output holds gate | up as column blocks, the silu*up (-> quant) kernels read those blocks through a
+    row stride, and the backward is one kernel writing dgate | dup into one buffer, ONE dgrad GEMM (K = 2*I: the two input
+    gradients are summed in the fp32 accumulators), ONE wgrad GEMM (M = 2*I) and one bias column sum.
+    models/int_llama_layer.py:44-45 + quantize/int_linear.py:48-65."""
+
+    @staticmethod
+    def forward(ctx, x, wg, bg, wu, bu, nbits, stash, sib=None):
+        ctx.sib = sib
+        x2 = x.contiguous().view(-1, x.shape[-1])
+        rows, K = x2.shape
+        wall = stacked_rows([wg, wu])
+        ball = stacked_vectors([bg, bu])
+        if wall is None or ball is False or wg.shape != wu.shape:
+            raise C.OQError("StackedGateUpFn: gate / up weights (and biases) must lie back to back in one buffer")
+        if wall.dtype != x2.dtype:
+            raise C.OQError(f"StackedGateUpFn: weight dtype {wall.dtype} != activation dtype {x2.dtype}")
+        I = wg.shape[0]
+        es = x2.element_size()
+        pre = torch.empty((rows, 2 * I), dtype=x2.dtype, device=x2.device)
+        gemm(x2, wall, pre, rows, 2 * I, K, K, K, 2 * I, True, True, bias=ball)
+        y = torch.empty((rows, I), dtype=x2.dtype, device=x2.device)
+        nbits = int(nbits or 0)
+        if nbits:
+            scale, zp, xmin, xmax = (torch.empty((rows, 1), dtype=torch.float32, device=x2.device) for _ in range(4))
+            C.call("oq_silu_mul_quant_fwd", pre.data_ptr(), pre.data_ptr() + I * es, C.dt(pre), rows, I, 2 * I, nbits, C.ptr(y),
+                   C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
+            if stash is not None:
+                stash["scale"], stash["zp"] = scale, zp
+            ctx.save_for_backward(x2, wg, wu, pre, xmin, xmax)
+        else:
+            C.call("oq_silu_mul_fwd_2d", pre.data_ptr(), pre.data_ptr() + I * es, C.ptr(y), C.dt(pre), rows, I, 2 * I, C.stream())
+            ctx.save_for_backward(x2, wg, wu, pre)
+        ctx.cfg = (nbits, bg is not None, x.shape)
+        return y.view(*x.shape[:-1], I)
+
+    @staticmethod
+    def backward(ctx, gy):
+        nbits, has_bias, xshape = ctx.cfg
+        if nbits:
+            x2, wg, wu, pre, xmin, xmax = ctx.saved_tensors
+        else:
+            x2, wg, wu, pre = ctx.saved_tensors
+        rows, K = x2.shape
+        I = wg.shape[0]
+        es = x2.element_size()
+        gy = gy.contiguous()
+        if gy.dtype != x2.dtype:
+            gy = gy.to(x2.dtype)
+        gpre = torch.empty((rows, 2 * I), dtype=x2.dtype, device=x2.device)
+        if nbits:
+            C.call("oq_silu_mul_quant_bwd", pre.data_ptr(), pre.data_ptr() + I * es, C.ptr(gy), C.dt(pre), rows, I, 2 * I, nbits,
+                   C.fptr(xmin), C.fptr(xmax), gpre.data_ptr(), gpre.data_ptr() + I * es, C.stream())
+        else:
+            C.call("oq_silu_mul_bwd_2d", pre.data_ptr(), pre.data_ptr() + I * es, C.ptr(gy), gpre.data_ptr(),
+                   gpre.data_ptr() + I * es, C.dt(pre), rows, I, 2 * I, C.stream())
+        need = ctx.needs_input_grad          # x, wg, bg, wu, bu
+        wall = stacked_rows([wg, wu])
+        gx = gwg = gwu = gbg = gbu = None
+        if need[0]:
+            gx2 = torch.empty((rows, K), dtype=x2.dtype, device=x2.device)
+            gemm(gpre, wall, gx2, rows, K, 2 * I, 2 * I, K, K, True, False)
+            gx = gx2.view(xshape)
+            if ctx.sib is not None:
+                gx = ctx.sib.offer(gx)
+        if need[1] or need[3]:
+            gwall = torch.empty((2 * I, K), dtype=wall.dtype, device=x2.device)
+            gemm(gpre, x2, gwall, 2 * I, K, rows, 2 * I, K, K, False, False)
+            gwg, gwu = (gwall[:I] if need[1] else None), (gwall[I:] if need[3] else None)
+        if has_bias and (need[2] or need[4]):
+            gb = torch.empty((2 * I,), dtype=torch.float32, device=x2.device)
+            ws_n = C.size_call("oq_colsum_workspace", rows, 2 * I)
+            wsb = torch.empty(ws_n, dtype=torch.float32, device=x2.device)
+            C.call("oq_colsum", C.ptr(gpre), C.dt(gpre), rows, 2 * I, C.fptr(gb), C.fptr(wsb), ws_n, C.stream())
+            gbg, gbu = (gb[:I] if need[2] else None), (gb[I:] if need[4] else None)
+        return gx, gwg, gbg, gwu, gbu, None, None, None
+
+
 class SiluMulQuantFn(torch.autograd.Function):
     """y = per_token_fake_quant(silu(gate) * up): QuantLlamaMLP's act_fn(gate) * up (models/int_llama_layer.py:44-45)
     fused with the down_proj input quantiser (quantize/int_linear.py:59-60, quantize/quantizer.py:84-147).  One kernel per
@@ -827,7 +975,7 @@ class SiluMulQuantFn(torch.autograd.Function):
         rows = gate.numel() // cols
         y = torch.empty_like(gate)
         scale, zp, xmin, xmax = (torch.empty((rows, 1), dtype=torch.float32, device=gate.device) for _ in range(4))
-        C.call("oq_silu_mul_quant_fwd", C.ptr(gate), C.ptr(up), C.dt(gate), rows, cols, int(nbits), C.ptr(y),
+        C.call("oq_silu_mul_quant_fwd", C.ptr(gate), C.ptr(up), C.dt(gate), rows, cols, 0, int(nbits), C.ptr(y),
                C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
         if stash is not None:
             stash["scale"], stash["zp"] = scale, zp
@@ -844,7 +992,7 @@ class SiluMulQuantFn(torch.autograd.Function):
         cols = gate.shape[-1]
         rows = gate.numel() // cols
         gg, gu = torch.empty_like(gate), torch.empty_like(up)
-        C.call("oq_silu_mul_quant_bwd", C.ptr(gate), C.ptr(up), C.ptr(gy), C.dt(gate), rows, cols, ctx.nbits,
+        C.call("oq_silu_mul_quant_bwd", C.ptr(gate), C.ptr(up), C.ptr(gy), C.dt(gate), rows, cols, 0, ctx.nbits,
                C.fptr(xmin), C.fptr(xmax), C.ptr(gg), C.ptr(gu), C.stream())
         return gg, gu, None, None
 
@@ -1053,7 +1201,10 @@ class LetVectorsFn(torch.autograd.Function):
             if x is not None and x.numel() != n:
                 raise NotImplementedError(f"LET vector of {x.numel()} elements in a block of hidden size {n}: LET needs "
                                           "equal q/k/v output widths (no grouped-query attention)")
-        outs = [torch.empty(n, dtype=torch.float32, device=s1.device) for _ in range(8)]
+        outs = [torch.empty(n, dtype=torch.float32, device=s1.device) for _ in range(4)]
+        b3 = torch.empty(3 * n, dtype=torch.float32, device=s1.device)     # b_q | b_k | b_v back to back: one bias vector
+        outs += [b3[:n], b3[n:2 * n], b3[2 * n:]]                           # for the stacked q/k/v GEMM (stacked_vectors)
+        outs.append(torch.empty(n, dtype=torch.float32, device=s1.device))
         C.call("oq_let_vectors_fwd", n, *[C.fptr(x) for x in ins], *[C.fptr(o) for o in outs], C.stream())
         ctx.save_for_backward(*[x for x in ins if x is not None])
         ctx.present = [x is not None for x in ins]

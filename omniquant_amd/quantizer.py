@@ -68,7 +68,7 @@ class UniformAffineQuantizer(nn.Module):
     def _identity(self):
         return self.n_bits >= 16 or not self.enable
 
-    def quantize(self, x, out_dtype=None, col_mul=None, row_div=None, row_mul=None, shift=None):
+    def quantize(self, x, out_dtype=None, col_mul=None, row_div=None, row_mul=None, shift=None, out=None):
         """Dynamic calibration + fake quant in ONE kernel, optionally fused with the LET weight transform
         x' = ((x*col_mul)/row_div)*row_mul and the by-product x @ shift.  Sets self.scale/round_zero_point.
 
@@ -76,7 +76,9 @@ class UniformAffineQuantizer(nn.Module):
         (quantize/quantizer.py:109-110): the tensor comes back unchanged (cast to out_dtype), scale / zero-point stay
         None; with LET arguments the transform still runs (kernel's identity grid).
         A ragged last group (in_features % group_size != 0, symmetric only as in the reference, :64-69) is zero-padded
-        inside the kernel exactly like :85-87 / :125-128."""
+        inside the kernel exactly like :85-87 / :125-128.
+        out: destination tensor of the fake-quantised values (block_common stacks sibling weights in one buffer); ignored
+        by the identity branch."""
         let = not (col_mul is None and row_div is None and row_mul is None and shift is None)
         if self._identity():
             self.scale = self.round_zero_point = None
@@ -91,7 +93,7 @@ class UniformAffineQuantizer(nn.Module):
         if self.group_size and x.shape[-1] % seg != 0:
             assert self.symmetric, "ragged weight groups are only defined for the symmetric grid (quantizer.py:69)"
         res = ops.fake_quant(x, self.n_bits, seg, up, low, self.symmetric, out_dtype, stash,
-                             col_mul, row_div, row_mul, shift)
+                             col_mul, row_div, row_mul, shift, out=out)
         self.scale, self.round_zero_point = stash["scale"], stash["zp"]
         return res
 

@@ -314,6 +314,39 @@ def test_multi_matrix_weight_quantiser_leaves_the_calibration_unchanged(monkeypa
         assert torch.equal(outs[0]["omni"][k_], outs[1]["omni"][k_]), k_
 
 
+def test_stacked_sibling_gemms_leave_the_calibration_unchanged(monkeypatch):
+    """q | k | v and gate | up fake-quant weights stacked in one buffer each, so that the sibling projections run as ONE
+    GEMM per direction (OQ_STACKED_GEMM, default on), against one GEMM per matrix: the forward is bit-identical (first loss
+    equal), the input gradients of the siblings are summed in fp32 accumulators instead of as bf16 terms, so the learned
+    tensors agree to within one optimiser step (lr 5e-3 / 1e-2) on average.  W4A4 + LET (QKVRopeQuantFn / StackedGateUpFn with the fused quantiser) and
+    W3A16g128 LWC-only (StackedGateUpFn without), hipGraph path."""
+    from omniquant_amd.calibrate import calibrate_block, default_args
+    from omniquant_amd.synthetic import make_config, make_layer, make_calib_inputs, causal_mask, synth_act_stats
+    from omniquant_amd.llama_block import QuantLlamaDecoderLayer
+    H = 1024
+    cfg = make_config(None, family="llama", hidden_size=H, inter=1536, heads=8, kv_heads=8)
+    Tn = 256
+    x = make_calib_inputs(3, Tn, H, dtype=torch.bfloat16).to(DEV)
+    mask = causal_mask(Tn).to(DEV)
+    pos = torch.arange(Tn, device=DEV)[None]
+    sc, sh = synth_act_stats(cfg, 1)
+    for kw in (dict(wbits=4, abits=4, lwc=True, let=True), dict(wbits=3, abits=16, group_size=128, lwc=True, let=False)):
+        args = default_args(epochs=2, nsamples=3, net="llama", **kw)
+        outs = []
+        for flag in ("0", "1"):
+            monkeypatch.setenv("OQ_STACKED_GEMM", flag)
+            q = QuantLlamaDecoderLayer(cfg, make_layer(cfg, seed=11, device=DEV), args).to(DEV)
+            outs.append(calibrate_block(q, args, "llama", 0, x.clone(), x.clone(), None, mask, pos, sc if kw["let"] else None,
+                                        sh if kw["let"] else None, use_graph=True))
+        la, lb = outs[0]["losses"], outs[1]["losses"]
+        assert all(math.isfinite(v) for v in la + lb)
+        assert abs(la[0] - lb[0]) <= 0.02 * abs(la[0]) and abs(la[-1] - lb[-1]) <= 0.05 * abs(la[-1]), (la, lb)
+        for k_ in outs[0]["omni"]:
+            a, b = outs[0]["omni"][k_].float(), outs[1]["omni"][k_].float()
+            # (AdamW's first updates are sign-like: a gradient of noise magnitude flips an element by 2 * lr per step)
+            assert float((a - b).abs().mean()) <= 5e-3 + 0.02 * float(a.abs().mean()), k_
+
+
 def test_real_quant_after_calibration():
     """--real_quant: after calibrate_layers every QuantLinear of the block is a PackedLinear whose dequantised weight
     equals the folded fake-quant weight (fp16 scales), for a grouped W4A16 LLaMA block."""

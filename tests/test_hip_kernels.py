@@ -524,6 +524,116 @@ def test_merged_qkv_rope_quant_matches_three_nodes(heads, use_sib):
         assert float((x1 - x2).abs().max()) <= 2e-2 * float(x1.abs().max())
 
 
+@pytest.mark.parametrize("heads", [(4, 4, 4), (8, 2, 2)])
+@pytest.mark.parametrize("use_sib", [False, True])
+def test_stacked_qkv_weights_run_as_one_gemm_per_direction(heads, use_sib):
+    """ops.QKVRopeQuantFn on q / k / v weights (and biases) that are row blocks of ONE buffer (what
+    block_common._weight_slabs hands the weight quantisers): one GEMM with N = Nq + Nk + Nv forward, one dgrad GEMM with
+    K = Nq + Nk + Nv, one wgrad GEMM with M = Nq + Nk + Nv -- against the same node on three separate tensors (one GEMM per
+    matrix): outputs, weight and bias gradients bit-identical (every element is accumulated over the contraction in the same
+    order); the input gradient is summed in the fp32 accumulators instead of rounding three bf16 terms first."""
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(33)
+    bs, T, K, hd = 1, 64, 512, 128
+    x = torch.randn(bs, T, K, generator=g).bfloat16().to(DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.outer(torch.arange(T).float(), inv)
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(DEV).contiguous(), emb.sin().to(DEV).contiguous()
+    Ns = [n * hd for n in heads]
+    Wall = (torch.randn(sum(Ns), K, generator=g) * 0.05).bfloat16().to(DEV)
+    Ball = torch.randn(sum(Ns), generator=g).to(DEV)
+    Gs = [torch.randn(bs, T, n, hd, generator=g).bfloat16().to(DEV) for n in heads]
+    offs = [0, Ns[0], Ns[0] + Ns[1], sum(Ns)]
+
+    def run(stacked):
+        xl = x.clone().requires_grad_(True)
+        if stacked:
+            wl, bl = Wall.clone().requires_grad_(True), Ball.clone().requires_grad_(True)
+            ws = [wl[offs[i]:offs[i + 1]] for i in range(3)]
+            bb = [bl[offs[i]:offs[i + 1]] for i in range(3)]
+            assert ops.stacked_rows(ws) is not None and ops.stacked_vectors(bb) is not False
+        else:
+            ws = [Wall[offs[i]:offs[i + 1]].clone().requires_grad_(True) for i in range(3)]
+            bb = [Ball[offs[i]:offs[i + 1]].clone().requires_grad_(True) for i in range(3)]
+            assert ops.stacked_rows(ws) is None
+        sib = ops.SiblingGrads() if use_sib else None
+        outs = ops.QKVRopeQuantFn.apply(xl, ws[0], bb[0], ws[1], bb[1], ws[2], bb[2], cos, sin, 4, hd, [{}, {}, {}], sib)
+        loss = sum((o.float() * G.float()).sum() for o, G in zip(outs, Gs))
+        loss.backward()
+        torch.cuda.synchronize()
+        gx = xl.grad.float().clone()
+        nparts = 0
+        if sib is not None:
+            for part in sib.take():
+                gx = gx + part.float()
+                nparts += 1
+        gw = wl.grad.clone() if stacked else torch.cat([w.grad for w in ws])
+        gb = bl.grad.clone() if stacked else torch.cat([b.grad for b in bb])
+        return [o.detach().clone() for o in outs], gw, gb, gx, nparts
+
+    o1, w1, b1, x1, p1 = run(False)
+    o2, w2, b2, x2, p2 = run(True)
+    for a, b in zip(o1 + [w1, b1], o2 + [w2, b2]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    if use_sib:
+        assert (p1, p2) == (2, 0)       # stacked: ONE input-gradient tensor, nothing left for the norm backward to add
+    assert float((x1 - x2).abs().max()) <= 2e-2 * float(x1.abs().max())
+    # the stacked dgrad is the better-rounded one: compare both with an fp32 reference of the sum
+    assert float((x1 - x2).norm()) <= 1e-2 * float(x1.norm())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("nbits", [4, 0])
+@pytest.mark.parametrize("use_sib", [False, True])
+def test_stacked_gate_up_matches_separate_projections(dtype, nbits, use_sib):
+    """ops.StackedGateUpFn (gate | up weights as row blocks of one buffer: one GEMM per direction, silu*up (-> per-token
+    quant) kernels reading / writing the column blocks of the stacked buffers through a row stride) against two ops.LinearFn
+    projections followed by ops.SiluMulQuantFn (nbits 4) or ops.SiluMulFn (nbits 0): activation and weight gradients
+    bit-identical, bias gradients equal up to fp32 summation order, input gradient equal up to the rounding of the two bf16
+    terms the separate path adds."""
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(5 + nbits)
+    T, K, I = 96, 256, 1032        # I is not a multiple of the GEMM's N-tile: the up block starts mid-tile
+    x = torch.randn(1, T, K, generator=g).to(dtype).to(DEV)
+    Wall = (torch.randn(2 * I, K, generator=g) * 0.08).to(dtype).to(DEV)
+    Ball = (torch.randn(2 * I, generator=g) * 0.1).to(DEV)
+    G = torch.randn(1, T, I, generator=g).to(dtype).to(DEV)
+
+    def run(stacked):
+        xl = x.clone().requires_grad_(True)
+        sib = ops.SiblingGrads() if use_sib else None
+        stash = {}
+        if stacked:
+            wl, bl = Wall.clone().requires_grad_(True), Ball.clone().requires_grad_(True)
+            y = ops.StackedGateUpFn.apply(xl, wl[:I], bl[:I], wl[I:], bl[I:], nbits, stash, sib)
+        else:
+            ws = [Wall[:I].clone().requires_grad_(True), Wall[I:].clone().requires_grad_(True)]
+            bb = [Ball[:I].clone().requires_grad_(True), Ball[I:].clone().requires_grad_(True)]
+            gate = ops.LinearFn.apply(xl, ws[0], bb[0], None, sib)
+            up = ops.LinearFn.apply(xl, ws[1], bb[1], None, sib)
+            y = ops.SiluMulQuantFn.apply(gate, up, nbits, stash) if nbits else ops.SiluMulFn.apply(gate, up)
+        (y.float() * G.float()).sum().backward()
+        torch.cuda.synchronize()
+        gx = xl.grad.float().clone()
+        if sib is not None:
+            for part in sib.take():
+                gx = gx + part.float()
+        gw = wl.grad.clone() if stacked else torch.cat([w.grad for w in ws])
+        gb = bl.grad.clone() if stacked else torch.cat([b.grad for b in bb])
+        return y.detach().clone(), gw, gb, gx, stash
+
+    y1, w1, b1, x1, s1 = run(False)
+    y2, w2, b2, x2, s2 = run(True)
+    assert torch.equal(y1, y2)
+    assert torch.equal(w1, w2)
+    assert torch.allclose(b1, b2, rtol=1e-5, atol=1e-5 * float(b1.abs().max()))   # one column sum over 2*I columns: other slabs
+    if nbits:
+        assert torch.equal(s1["scale"], s2["scale"]) and torch.equal(s1["zp"], s2["zp"])
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert float((x1 - x2).norm()) <= tol * float(x1.norm())
+
+
 def test_bad_arguments_raise():
     """Error convention of the boundary: negative rc -> OQError with the library's message; CPU tensors refused."""
     from omniquant_amd import ops, OQError, _capi as C
