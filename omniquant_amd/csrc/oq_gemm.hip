@@ -28,6 +28,19 @@ int dbg_env_i(const char* name, int dflt) {     // tuning / A-B switches (read p
     return v ? atoi(v) : dflt;
 }
 
+// Diagnostic build only (tools/gemm_stamps.hip compiles this file with -DOQ_GEMM_STAMPS): wave 0 of every workgroup writes
+// s_memrealtime (100 MHz) at a few points into a buffer of its own.  In the product library no stamp executes.
+#ifdef OQ_GEMM_STAMPS
+__device__ unsigned long long* g_gemm_stamps = nullptr;      // [workgroup][8]
+#define OQ_STAMP(slot)                                                                                      \
+    do {                                                                                                    \
+        if (g_gemm_stamps && threadIdx.x == 0)                                                              \
+            g_gemm_stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();              \
+    } while (0)
+#else
+#define OQ_STAMP(slot) do { } while (0)
+#endif
+
 struct GemmP {
     const void* a;
     const void* b;
@@ -39,6 +52,7 @@ struct GemmP {
     float alpha;
     int64_t batch_i, sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
     int tiles_n, tiles_m, nmajor, tri;
+    int epi_lds;             // gemm_bf16_p3_kernel: store the output tile through LDS in whole 128-byte lines
 };
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -375,6 +389,7 @@ __device__ __forceinline__ bf16x8 frag_read(const uint32_t (&b)[4], uint32_t sta
 template <bool AKC, bool BKC, typename TOUT, bool STAGGER, bool SPLIT>
 __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[3 * P3_STAGE];   // ONE array: see cdna guide (second-object trap)
+    OQ_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;
@@ -462,6 +477,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    OQ_STAMP(1);
     if (grp_b) __builtin_amdgcn_s_barrier();      // group B idles through interval 0
     int s_cur = 0, s_pre = 2;
     for (int t = 0; t < nt; ++t) {
@@ -536,6 +552,73 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
         s_pre = s_pre == 2 ? 0 : s_pre + 1;
     }
     if (STAGGER && !grp_b) __builtin_amdgcn_s_barrier();     // group A's matching extra barrier
+    OQ_STAMP(2);
+    if (p.epi_lds) {
+        // ---- epilogue through LDS: every global store covers whole 128-byte lines ---------------------------------
+        // The MFMA accumulators hold, per lane, 4 consecutive columns of ONE row: stored from there, a wave instruction
+        // touches 16 rows x 32 bytes (16 partial lines; measured 3.5-4.8 us per tile, every CU bursting at once).  After the
+        // final barrier nobody reads the operand ring any more, so each wave parks its 64 x 64 fp32 block in a 17 KiB region
+        // of its own (row stride 272 B: conflict-free ds_write_b128), reads it back row-wise and stores 16 B (bf16: 8 lanes
+        // per 128-byte row) or 2 x 16 B (f32) per lane.  Same arithmetic, same single rounding: bit-identical results.
+        constexpr int RS = 272;
+        char* epi = smem + wid * (64 * RS);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int64_t nb = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (p.bias && nb < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + nb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][j][r] * p.alpha;
+                    if (p.bias) v[r] += bv[r];
+                }
+                *reinterpret_cast<f32x4*>(epi + (i * 16 + (lane & 15)) * RS + (j * 16 + (lane >> 4) * 4) * 4) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t n = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = q * 8 + (lane >> 3);
+            const int64_t m = m0 + wm * 64 + row;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(epi + row * RS + (lane & 7) * 32);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(epi + row * RS + (lane & 7) * 32 + 16);
+            if (m >= p.M || n >= p.N) continue;
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            TOUT* dst = C + m * p.ldc + n;
+            if (p.addend) {
+                const TOUT* ad = reinterpret_cast<const TOUT*>(p.addend) + (C - reinterpret_cast<TOUT*>(p.c)) + m * p.ldc + n;
+                if constexpr (sizeof(TOUT) == 4) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(ad), a1 = *reinterpret_cast<const f32x4*>(ad + 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] += a0[r]; v[4 + r] += a1[r]; }
+                } else {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(ad);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += (float)av[r];
+                }
+            }
+            if constexpr (sizeof(TOUT) == 4) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            } else {
+                bf16x8 o;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
+                *reinterpret_cast<bf16x8*>(dst) = o;
+            }
+        }
+        OQ_STAMP(3);
+#ifdef OQ_GEMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        OQ_STAMP(4);
+#endif
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -572,6 +655,11 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
             }
         }
     }
+    OQ_STAMP(3);
+#ifdef OQ_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OQ_STAMP(4);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -975,6 +1063,10 @@ extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias
                 OQ_CHECK_LAUNCH("oq_gemm(pp)");
                 return OQ_OK;
             }
+            // whole-line stores need 8-element granularity of every output address (and of the addend, which shares them)
+            p.epi_lds = (dbg_env_i("OQ_GEMM_EPI_LDS", 1) != 0 && N % 8 == 0 && ldc % 8 == 0 && sc_o % 8 == 0 && sc_i % 8 == 0 &&
+                         (reinterpret_cast<uintptr_t>(c) & 15) == 0 && (!addend || (reinterpret_cast<uintptr_t>(addend) & 15) == 0) &&
+                         (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) ? 1 : 0;
             const bool stagger = dbg_env_i("OQ_GEMM_STAGGER", 1) != 0;
             const bool split = dbg_env_i("OQ_GEMM_SPLIT", 1) != 0;
 #define LAUNCH_P3(AK, BK_, T)                                                                                          \
