@@ -184,7 +184,9 @@ int oq_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64_t T, int n
 /* oq_qkv_rope_quant_fwd/bwd: the same for q, k and v in ONE launch per direction.  x (and gx) is the merged projection
  * output [rows, nhq + nhk + nhv, 128] (the three GEMMs write column blocks of one buffer); q and k heads are rotated, v
  * heads are not (models/int_llama_layer.py:124-125); the quantised tensors / their gradients stay three contiguous
- * [rows, nh_i, 128] buffers as the attention kernels expect.  scale / zp / xmin / xmax: [rows * (nhq + nhk + nhv)]. */
+ * [rows, nh_i, 128] buffers as the attention kernels expect.  scale / zp / xmin / xmax: [rows * (nhq + nhk + nhv)].
+ * nbits == 16 (these two entry points only) is the identity grid of quantize/quantizer.py:109-110: rotate and split only
+ * (weight-only configurations run q | k | v as one stacked GEMM too); scale / zp / xmin / xmax may then be NULL. */
 int oq_qkv_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nhq, int nhk, int nhv, int hd,
                           const float* cos, const float* sin, int nbits, void* yq, void* yk, void* yv, int y_dtype,
                           float* scale, float* zp, float* xmin, float* xmax, void* stream);

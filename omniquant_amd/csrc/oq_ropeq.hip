@@ -93,6 +93,11 @@ __global__ void __launch_bounds__(256) ropeq_fwd_kernel(RQ p) {
         rotated<TIN>(p, seg, l, x);
         const HeadSel hs = head_sel(p, (int)(seg % p.nh));
         TOUT* yseg = (hs.t == 0 ? ybase : reinterpret_cast<TOUT*>(hs.t == 1 ? p.y1 : p.y2)) + ((seg / p.nh) * hs.nht + hs.hl) * HD;
+        if (p.nbits >= 16) {                            // identity grid (weight-only configurations): rotate and split only
+#pragma unroll
+            for (int c = 0; c < NC; ++c) Vec8<TOUT>::store(yseg + (c * 4 + l) * 8, x[c]);
+            continue;
+        }
         float hi = -INFINITY, lo = INFINITY;
         uint64_t nanm = 0;
 #pragma unroll
@@ -153,10 +158,11 @@ __global__ void __launch_bounds__(256) ropeq_bwd_kernel(RQ p) {
         int64_t seg = s0 + (lane >> 2);
         if (seg >= nseg) seg = nseg - 1;
         float x[NC][8], gin[NC][8];
-        rotated<TIN>(p, seg, l, x);
-        const float hi = p.xmax[seg], lo = p.xmin[seg];
+        const bool ident = p.nbits >= 16;               // identity grid: dL/dx is the transposed rotation of dL/dy
+        if (!ident) rotated<TIN>(p, seg, l, x);
+        const float hi = ident ? 0.f : p.xmax[seg], lo = ident ? 0.f : p.xmin[seg];
         float inv_s = 0.f;
-        const QP q = make_qp(hi, lo, false, 0.f, 0.f, p.nbits, 0, p.inv_q, &inv_s);
+        const QP q = make_qp(hi, lo, false, 0.f, 0.f, ident ? 8 : p.nbits, 0, p.inv_q, &inv_s);
         // scale == 0 (quirk Q1): round_ste turns x / 0 = +-inf into NaN; a NaN zero-point inside round(t) + z gives the same
         // all-NaN segment without a per-element select ((r - t) + t == r for every finite t)
         const float zr = q.s == 0.f ? NAN : q.z;
@@ -168,6 +174,11 @@ __global__ void __launch_bounds__(256) ropeq_bwd_kernel(RQ p) {
         for (int c = 0; c < NC; ++c) {
             float G[8];
             Vec8<TG>::load(gseg + (c * 4 + l) * 8, G);
+            if (ident) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gin[c][i] = G[i];
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float tq = x[c][i] * inv_s;
@@ -180,17 +191,19 @@ __global__ void __launch_bounds__(256) ropeq_bwd_kernel(RQ p) {
                 clo += x[c][i] == lo ? 1.f : 0.f;
             }
         }
-        gs = wave_sum(gs, LPS);
-        chi = wave_sum(chi, LPS);
-        clo = wave_sum(clo, LPS);
-        const float tie_hi = (gs / Q) / chi, tie_lo = -(gs / Q) / clo;
+        if (!ident) {
+            gs = wave_sum(gs, LPS);
+            chi = wave_sum(chi, LPS);
+            clo = wave_sum(clo, LPS);
+            const float tie_hi = (gs / Q) / chi, tie_lo = -(gs / Q) / clo;
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (x[c][i] == hi) gin[c][i] += tie_hi;
-                if (x[c][i] == lo) gin[c][i] += tie_lo;
-            }
+                for (int i = 0; i < 8; ++i) {
+                    if (x[c][i] == hi) gin[c][i] += tie_hi;
+                    if (x[c][i] == lo) gin[c][i] += tie_lo;
+                }
+        }
         if (p.cs && head < p.nrope) {
             // transposed rotation: gx_e = g_e cos_e - sgn_e * g_partner * sin_e   (cos / sin are equal on both halves)
             const int64_t t = (seg / p.nh) % p.T;
@@ -212,14 +225,14 @@ __global__ void __launch_bounds__(256) ropeq_bwd_kernel(RQ p) {
     }
 }
 
-int check(const char* fn, int64_t rows, int64_t T, int nh, int hd, int nbits, const float* cs, const float* sn) {
+int check(const char* fn, int64_t rows, int64_t T, int nh, int hd, int nbits, const float* cs, const float* sn, bool ident_ok = false) {
     OQ_CHECK_ARG(rows > 0 && T > 0 && nh > 0 && rows % T == 0, "%s: rows %lld must be a positive multiple of T %lld", fn,
                  (long long)rows, (long long)T);
     if (hd != HD) {
         oq_set_error("%s: head_dim %d unsupported (only 128)", fn, hd);
         return OQ_E_UNSUPPORTED;
     }
-    OQ_CHECK_ARG(nbits >= 2 && nbits < 16, "%s: bitwidth %d", fn, nbits);
+    OQ_CHECK_ARG(nbits >= 2 && (nbits < 16 || (ident_ok && nbits == 16)), "%s: bitwidth %d", fn, nbits);
     OQ_CHECK_ARG((cs == nullptr) == (sn == nullptr), "%s: cos / sin must both be given or both NULL", fn);
     return OQ_OK;
 }
@@ -291,9 +304,9 @@ extern "C" int oq_qkv_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, i
                                      float* scale, float* zp, float* xmin, float* xmax, void* stream) {
     OQ_CHECK_ARG(nhq > 0 && nhk > 0 && nhv > 0, "oq_qkv_rope_quant_fwd: head counts %d / %d / %d", nhq, nhk, nhv);
     const int nh = nhq + nhk + nhv;
-    const int rc = check("oq_qkv_rope_quant_fwd", rows, T, nh, hd, nbits, cos, sin);
+    const int rc = check("oq_qkv_rope_quant_fwd", rows, T, nh, hd, nbits, cos, sin, true);
     if (rc) return rc;
-    OQ_CHECK_ARG(x && yq && yk && yv && scale && zp && xmin && xmax && cos && sin, "oq_qkv_rope_quant_fwd: null pointer");
+    OQ_CHECK_ARG(x && yq && yk && yv && cos && sin && (nbits == 16 || (scale && zp && xmin && xmax)), "oq_qkv_rope_quant_fwd: null pointer");
     OQ_CHECK_ARG(oq_aligned16(x) && oq_aligned16(yq) && oq_aligned16(yk) && oq_aligned16(yv) && oq_aligned16(cos) && oq_aligned16(sin),
                  "oq_qkv_rope_quant_fwd: 16-byte alignment");
     RQ p{};
@@ -320,9 +333,9 @@ extern "C" int oq_qkv_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, i
                                      const void* gq, const void* gk, const void* gv, int g_dtype, void* gx, void* stream) {
     OQ_CHECK_ARG(nhq > 0 && nhk > 0 && nhv > 0, "oq_qkv_rope_quant_bwd: head counts %d / %d / %d", nhq, nhk, nhv);
     const int nh = nhq + nhk + nhv;
-    const int rc = check("oq_qkv_rope_quant_bwd", rows, T, nh, hd, nbits, cos, sin);
+    const int rc = check("oq_qkv_rope_quant_bwd", rows, T, nh, hd, nbits, cos, sin, true);
     if (rc) return rc;
-    OQ_CHECK_ARG(x && gq && gk && gv && gx && xmin && xmax && cos && sin, "oq_qkv_rope_quant_bwd: null pointer");
+    OQ_CHECK_ARG(x && gq && gk && gv && gx && cos && sin && (nbits == 16 || (xmin && xmax)), "oq_qkv_rope_quant_bwd: null pointer");
     OQ_CHECK_ARG(oq_aligned16(x) && oq_aligned16(gq) && oq_aligned16(gk) && oq_aligned16(gv) && oq_aligned16(gx),
                  "oq_qkv_rope_quant_bwd: 16-byte alignment");
     RQ p{};

@@ -131,6 +131,22 @@ class QuantLlamaAttention(nn.Module):
                 return False
         return ops.rope_quant_supported(hq.dtype, self.head_dim)
 
+    def _fused_rope_split(self, hq):
+        """True when q / k / v can take the same node on the IDENTITY grid: the three head quantisers are off (or >= 16 bit:
+        weight-only configurations, quantize/quantizer.py:109-110), head_dim 128, HIP GEMM projections, bf16.  The projections
+        then run as one stacked GEMM per direction and RoPE + the q | k | v split are one launch per direction."""
+        from .linear import _hip_linear
+        if os.environ.get("OQ_MERGED_QKV", "1") == "0" or hq.dtype != torch.bfloat16:
+            return False
+        for mm, qz in ((self.qkt_matmul, self.qkt_matmul.x1_quantizer), (self.qkt_matmul, self.qkt_matmul.x2_quantizer),
+                       (self.pv_matmul, self.pv_matmul.x2_quantizer)):
+            if mm.use_act_quant and qz.enable and qz.n_bits < 16:
+                return False
+        for lin in (self.q_proj, self.k_proj, self.v_proj):
+            if lin.fwd_func is not _hip_linear or lin.fwd_kwargs or lin.__dict__.get("_stat_sink") is not None:
+                return False
+        return ops.rope_quant_supported(hq.dtype, self.head_dim)
+
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
                 output_attentions=False, use_cache=False, residual=None, input_is_quantized=False, sib=None):
         if past_key_value is not None or use_cache or output_attentions:
@@ -140,7 +156,16 @@ class QuantLlamaAttention(nn.Module):
         hq = hidden_states if input_is_quantized else self.q_proj.quantize_input(hidden_states)   # q/k/v share one pass
         cos, sin = self._rope_tables(position_ids, q_len, hidden_states.device)
         fused_qkv = self._fused_rope_quant(hq)
-        if fused_qkv:
+        split_qkv = (not fused_qkv) and self._fused_rope_split(hq)
+        if split_qkv:
+            wbs = []
+            for lin in (self.q_proj, self.k_proj, self.v_proj):
+                w, b = lin._resolve(hq.dtype)
+                wbs.append((w if w.dtype == hq.dtype else ops.cast(w, hq.dtype), b))
+            q, k, v = ops.QKVRopeQuantFn.apply(hq, wbs[0][0], wbs[0][1], wbs[1][0], wbs[1][1], wbs[2][0], wbs[2][1], cos, sin,
+                                               16, hd, None, sib)
+            fused_qkv = True            # (q, k, v are final: the head quantisers are the identity)
+        elif fused_qkv:
             # projection -> RoPE -> head-wise fake quant as one node per tensor: the projection output stays fp32 inside it
             trio = ((self.q_proj, self.qkt_matmul.x1_quantizer, True), (self.k_proj, self.qkt_matmul.x2_quantizer, True),
                     (self.v_proj, self.pv_matmul.x2_quantizer, False))

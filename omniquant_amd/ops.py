@@ -475,25 +475,36 @@ class QKVRopeQuantFn(torch.autograd.Function):
         nhs = [N // hd for N in Ns]
         nht = sum(nhs)
         ys = [torch.empty((rows, N), dtype=x2.dtype, device=x2.device) for N in Ns]
-        scale, zp, xmin, xmax = (torch.empty((rows * nht, 1), dtype=torch.float32, device=x2.device) for _ in range(4))
+        ident = int(nbits) >= 16          # identity grid: rotate + split only (weight-only configurations)
+        nbits = 16 if ident else int(nbits)
+        scale, zp, xmin, xmax = ((None,) * 4 if ident else
+                                 tuple(torch.empty((rows * nht, 1), dtype=torch.float32, device=x2.device) for _ in range(4)))
         T = x.shape[-2]
         C.call("oq_qkv_rope_quant_fwd", C.ptr(pre), C.dt(pre), rows, T, nhs[0], nhs[1], nhs[2], hd, C.fptr(cos), C.fptr(sin),
                int(nbits), C.ptr(ys[0]), C.ptr(ys[1]), C.ptr(ys[2]), C.dt(ys[0]), C.fptr(scale), C.fptr(zp), C.fptr(xmin),
                C.fptr(xmax), C.stream())
-        if stashes is not None:
+        if stashes is not None and not ident:
             h0 = 0
             sv, zv = scale.view(rows, nht, 1), zp.view(rows, nht, 1)
             for st, n in zip(stashes, nhs):
                 st["scale"], st["zp"] = sv[:, h0:h0 + n], zv[:, h0:h0 + n]       # views of the merged per-(token, head) vectors
                 h0 += n
-        ctx.save_for_backward(x2, *ws, pre, xmin, xmax, cos, sin)
+        if ident:
+            ctx.save_for_backward(x2, *ws, cos, sin)        # the backward of rotate + split needs no forward values
+        else:
+            ctx.save_for_backward(x2, *ws, pre, xmin, xmax, cos, sin)
         ctx.cfg = (T, tuple(nhs), hd, int(nbits), tuple(b is not None for b in bs_), x.shape, tuple(offs))
         return tuple(y.view(*x.shape[:-1], n, hd) for y, n in zip(ys, nhs))
 
     @staticmethod
     def backward(ctx, gq, gk, gv):
-        x2, wq, wk, wv, pre, xmin, xmax, cos, sin = ctx.saved_tensors
         T, nhs, hd, nbits, has_bias, xshape, offs = ctx.cfg
+        if nbits >= 16:
+            x2, wq, wk, wv, cos, sin = ctx.saved_tensors
+            pre = x2                                        # not read by the identity-grid backward; any valid pointer
+            xmin = xmax = None
+        else:
+            x2, wq, wk, wv, pre, xmin, xmax, cos, sin = ctx.saved_tensors
         rows, K = x2.shape
         ws = (wq, wk, wv)
         Ns = [w.shape[0] for w in ws]

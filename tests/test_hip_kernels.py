@@ -634,6 +634,50 @@ def test_stacked_gate_up_matches_separate_projections(dtype, nbits, use_sib):
     assert float((x1 - x2).norm()) <= tol * float(x1.norm())
 
 
+@pytest.mark.parametrize("heads", [(4, 4, 4), (8, 2, 2)])
+def test_qkv_rope_split_identity_grid_matches_unfused_chain(heads):
+    """ops.QKVRopeQuantFn with nbits = 16 (identity grid: the weight-only configurations' q / k / v path -- one stacked GEMM,
+    RoPE + split in one launch per direction) against the unfused chain it replaces (three ops.LinearFn projections,
+    ops.RopeFn on q and k; models/int_llama_layer.py:116-125): outputs and weight / bias gradients bit-identical, the input
+    gradient equal up to the bf16 rounding of the three terms the unfused chain adds."""
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(44)
+    bs, T, K, hd = 1, 64, 512, 128
+    x = torch.randn(bs, T, K, generator=g).bfloat16().to(DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.outer(torch.arange(T).float(), inv)
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(DEV).contiguous(), emb.sin().to(DEV).contiguous()
+    Ns = [n * hd for n in heads]
+    offs = [0, Ns[0], Ns[0] + Ns[1], sum(Ns)]
+    Wall = (torch.randn(sum(Ns), K, generator=g) * 0.05).bfloat16().to(DEV)
+    Ball = torch.randn(sum(Ns), generator=g).to(DEV)
+    Gs = [torch.randn(bs, T, n, hd, generator=g).bfloat16().to(DEV) for n in heads]
+
+    def run(fused):
+        xl = x.clone().requires_grad_(True)
+        wl, bl = Wall.clone().requires_grad_(True), Ball.clone().requires_grad_(True)
+        ws = [wl[offs[i]:offs[i + 1]] for i in range(3)]
+        bb = [bl[offs[i]:offs[i + 1]] for i in range(3)]
+        if fused:
+            outs = ops.QKVRopeQuantFn.apply(xl, ws[0], bb[0], ws[1], bb[1], ws[2], bb[2], cos, sin, 16, hd, None, None)
+        else:
+            pre = [ops.LinearFn.apply(xl, ws[i], bb[i], None, None).view(bs, T, heads[i], hd) for i in range(3)]
+            outs = [ops.RopeFn.apply(pre[0], cos, sin), ops.RopeFn.apply(pre[1], cos, sin), pre[2]]
+        loss = sum((o.float() * G.float()).sum() for o, G in zip(outs, Gs))
+        loss.backward()
+        torch.cuda.synchronize()
+        return [o.detach().clone() for o in outs], wl.grad.clone(), bl.grad.clone(), xl.grad.float().clone()
+
+    o1, w1, b1, x1 = run(False)
+    o2, w2, b2, x2 = run(True)
+    for a, b in zip(o1, o2):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(w1, w2)
+    assert torch.allclose(b1, b2, rtol=1e-5, atol=1e-5 * float(b1.abs().max()))
+    assert float((x1 - x2).norm()) <= 1e-2 * float(x1.norm())
+
+
 def test_bad_arguments_raise():
     """Error convention of the boundary: negative rc -> OQError with the library's message; CPU tensors refused."""
     from omniquant_amd import ops, OQError, _capi as C
