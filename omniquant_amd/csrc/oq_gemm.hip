@@ -52,7 +52,7 @@ struct GemmP {
     float alpha;
     int64_t batch_i, sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
     int tiles_n, tiles_m, nmajor, tri;
-    int blk48;               // gemm_bf16_p3_kernel: 4 x 8-tile blocks per XCD round (see the kernel)
+    int blk48;               // gemm_bf16_p3_kernel: strip-ordered tile ids, ~4 x 8-tile blocks per XCD round (see the kernel)
     int epi_lds;             // gemm_bf16_p3_kernel: store the output tile through LDS in whole 128-byte lines
 };
 
@@ -401,11 +401,16 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
     }
     int64_t m0, n0;
     if (p.blk48) {
-        // the 32 tiles an XCD runs at a time form a 4 x 8 block of tiles (1024 x 1024 outputs): 4 A-tiles + 8 B-tiles = 256 KB
-        // of operands per K-step through that XCD's L2 instead of 8 + 4 tiles = 320 KB with the n-major strip
-        const int blk = tile >> 5, l = tile & 31, bpm = p.tiles_m >> 2;
-        m0 = (int64_t)((blk % bpm) * 4 + (l & 3)) * P3_BM;
-        n0 = (int64_t)((blk / bpm) * 8 + (l >> 2)) * P3_BN;
+        // tiles are numbered strip by strip (a strip = 8 n-tiles wide, the last one narrower), m-major inside a strip: ANY 32
+        // consecutive ids -- what an XCD runs at a time -- cover about 4 x 8 tiles (1024 x 1024 outputs): 4 A-tiles + 8 B-tiles
+        // = 256 KB of operands per K-step through that XCD's L2 instead of 8 + 4 tiles = 320 KB with plain n-major order.
+        // No alignment of the tile counts is needed.
+        const int W = p.blk48;                          // strip width in n-tiles (8)
+        const int ssz = p.tiles_m * W, strip = tile / ssz, rem = tile - strip * ssz;
+        const int w = p.tiles_n - strip * W < W ? p.tiles_n - strip * W : W;
+        const int mi = rem / w;
+        m0 = (int64_t)mi * P3_BM;
+        n0 = (int64_t)(strip * W + (rem - mi * w)) * P3_BN;
     } else if (p.nmajor) { n0 = (int64_t)(tile / p.tiles_m) * P3_BN; m0 = (int64_t)(tile % p.tiles_m) * P3_BM; }
     else { m0 = (int64_t)(tile / p.tiles_n) * P3_BM; n0 = (int64_t)(tile % p.tiles_n) * P3_BN; }
     const int64_t bo = blockIdx.z / p.batch_i, bi = blockIdx.z % p.batch_i;
@@ -1074,8 +1079,10 @@ extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias
             p.epi_lds = (dbg_env_i("OQ_GEMM_EPI_LDS", 1) != 0 && N % 8 == 0 && ldc % 8 == 0 && sc_o % 8 == 0 && sc_i % 8 == 0 &&
                          (reinterpret_cast<uintptr_t>(c) & 15) == 0 && (!addend || (reinterpret_cast<uintptr_t>(addend) & 15) == 0) &&
                          (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) ? 1 : 0;
-            p.blk48 = (dbg_env_i("OQ_GEMM_BLK48", 1) != 0 && tri_mode == 0 && tm3 % 4 == 0 && tn3 % 8 == 0 && (tm3 * tn3) % 256 == 0 &&
-                       M % P3_BM == 0 && N % P3_BN == 0) ? 1 : 0;
+            {
+                const int sw = dbg_env_i("OQ_GEMM_BLK48", 8);          // 0: plain n-/m-major order; else the strip width
+                p.blk48 = (tri_mode == 0 && sw > 0) ? (sw == 1 ? 8 : sw) : 0;
+            }
             const bool stagger = dbg_env_i("OQ_GEMM_STAGGER", 1) != 0;
             const bool split = dbg_env_i("OQ_GEMM_SPLIT", 1) != 0;
 #define LAUNCH_P3(AK, BK_, T)                                                                                          \
