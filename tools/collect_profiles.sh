@@ -23,5 +23,6 @@ python tools/microbench_rowq.py > $out/r2_quant_microbench.txt 2>&1
 for c in llama-7b-w3a16g128 llama-2-13b-w4a4 llama-2-70b-w2a16g64 opt-125m-w4a16; do python bench.py --config $c --steps 256 --warmup 32 --no-cpu-baseline 2>/dev/null; done > $out/r2_bench_configs.jsonl
 python tools/blaslt_ceiling.py > $out/r2_gemm_vs_hipblaslt.txt 2>&1
 python tools/soak.py 3 3 > $out/r2_soak.txt 2>&1
+./tools/gemm_stamps.bin > $out/r2_gemm_tile_stamps.txt 2>&1
 ls -la $out | head -40
 cut -c1-300 $out/r2_bench_default.json
