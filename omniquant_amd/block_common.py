@@ -226,8 +226,8 @@ class QuantBlockMixin:
                 side.wait_stream(main)
             lazy_mlp = bool(self.__dict__.get("_lazy_mlp_quant")) and not forked
             mlp = set(nm["fc1"]) | {nm["last"]} if lazy_mlp else set()
-            dest = self._weight_slabs(nm, dt)
             with torch.cuda.stream(side):
+                dest = self._weight_slabs(nm, dt)      # (allocated on the stream that writes them)
                 mods = list(self._quant_linears())
                 if os.environ.get("OQ_WQ_ORDER", "1") != "0":       # last-used-first, see _let_temporaries
                     rank = {nm["o"]: 0, nm["v"]: 1, nm["k"]: 2, nm["q"]: 3}

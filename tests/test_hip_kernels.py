@@ -131,6 +131,31 @@ def test_gemm_layouts(dtype, a_kc, b_kc, M, N, K):
         assert_close(c.float(), want.numpy(), tol, tol, f"gemm {dtype} akc={a_kc} bkc={b_kc} out={out_dtype}")
 
 
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(768, 1408, 128), (2304, 2688, 64), (520, 3080, 192), (4096, 1032, 64)])
+def test_gemm_strip_ordered_tiles_and_lds_epilogue_exact(a_kc, b_kc, M, N, K):
+    """The 256x128 MFMA kernel on tile grids that are ragged in every way the strip-ordered tile ids (8 n-tiles per strip,
+    m-major inside, narrower last strip) and the LDS epilogue (whole-line stores, M / N edges inside a tile) have to get
+    right: several strips, a last strip of 3 / 5 / 1 n-tiles, more tiles than CUs, partial edge tiles.  Integer-valued
+    operands make every output exact in fp32, so a tile computed twice, skipped or stored at the wrong place is an exact
+    mismatch; bias, alpha = 1 and the addend (output accumulation) go through the same epilogue."""
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    bias = torch.randint(-5, 6, (N,), generator=g).float()
+    add = torch.randint(-9, 10, (M, N), generator=g).float()
+    want = A @ B.T + bias[None, :] + add
+    a = (A if a_kc else A.T.contiguous()).bfloat16().to(DEV)
+    b = (B if b_kc else B.T.contiguous()).bfloat16().to(DEV)
+    c = add.clone().to(DEV)
+    ops.gemm(a, b, c, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc, b_kc, bias=bias.to(DEV), addend=c)
+    assert torch.equal(c.cpu(), want)
+    cb = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a, b, cb, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc, b_kc)
+    assert torch.equal(cb.cpu().float(), (A @ B.T).bfloat16().float())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("nh,nkv", [(4, 4), (8, 2)])
 def test_attention_gemms(dtype, nh, nkv):
