@@ -443,10 +443,14 @@ class LinearRopeQuantFn(torch.autograd.Function):
 
 
 class QKVRopeQuantFn(torch.autograd.Function):
-    """q, k, v = LinearRopeQuantFn three times, as ONE autograd node: the three projections write column blocks of one
+    """q, k, v = LinearRopeQuantFn three times, as ONE autograd node: the projections write column blocks of one
     [rows, Nq + Nk + Nv] buffer, RoPE + head-wise fake quant of all heads is one launch per direction
-    (oq_qkv_rope_quant_*), the bias gradients one column sum; the GEMMs stay one per matrix (their weights are separate
-    tensors).  Same arithmetic per element, so results are bit-identical to the three separate nodes.
+    (oq_qkv_rope_quant_*), the bias gradients one column sum.  When the three fake-quant weights (and biases) lie back to back
+    in one buffer (stacked_rows: block_common._weight_slabs hands such destinations to the weight quantisers) the projections
+    are ONE GEMM per direction: N = Nq + Nk + Nv forward, K = that sum for dX (the three input gradients are added in the
+    fp32 accumulators), M = that sum for dW; otherwise one GEMM per matrix into / out of the shared buffer, bit-identical to
+    three separate nodes.  nbits >= 16 is the identity grid (quantize/quantizer.py:109-110): rotate and split only -- the
+    weight-only configurations' path (models/int_llama_layer.py:116-125).
     x [bs, T, K]; returns q [bs, T, nhq, hd], k, v [bs, T, nhk|nhv, hd]."""
 
     @staticmethod
