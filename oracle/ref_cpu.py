@@ -612,8 +612,9 @@ def train_step(block, opt, x, target, mask, pos, target2=None):
 
 
 def calibrate(family, cfg, layer_weights, spec, inps, mask, pos, act_scales=None, act_shifts=None,
-              epochs=2, let_lr=5e-3, lwc_lr=1e-2, wd=0.0, alpha=0.5, aug_loss=False, prefix="model.layers"):
-    """Sequential block-wise calibration (bs=1).  Returns dict with per-step losses/norms, the
+              epochs=2, let_lr=5e-3, lwc_lr=1e-2, wd=0.0, alpha=0.5, aug_loss=False, prefix="model.layers", batch_size=1):
+    """Sequential block-wise calibration.  batch_size samples per step with the mask repeated per sample
+    (quantize/omniquant.py:139-141,214-219).  Returns dict with per-step losses/norms, the
     fp16 omni_state_dict per layer, folded weights, qparams and the propagated activations."""
     quant_inps = inps.clone()
     fp_inps = inps.clone()
@@ -632,10 +633,12 @@ def calibrate(family, cfg, layer_weights, spec, inps, mask, pos, act_scales=None
             blk.register_let(act_scales, act_shifts, alpha, i, prefix)
         opt = AdamW([{"params": blk.let_params(), "lr": let_lr}, {"params": blk.lwc_params(), "lr": lwc_lr}],
                     weight_decay=wd)
+        bs = batch_size
+        mask_b = mask.repeat(bs, 1, 1, 1) if (bs > 1 and mask is not None) else mask
         for _ in range(epochs):
-            for j in range(n):
-                l, g = train_step(blk, opt, quant_inps[j:j + 1], fp_inps[j:j + 1], mask, pos,
-                                  fp_inps_2[j:j + 1] if aug_loss else None)
+            for j in range(0, n // bs * bs, bs):
+                l, g = train_step(blk, opt, quant_inps[j:j + bs], fp_inps[j:j + bs], mask_b, pos,
+                                  fp_inps_2[j:j + bs] if aug_loss else None)
                 res["losses"].append(l)
                 res["norms"].append(g)
         res["trained"].append(OrderedDict((k, v.detach().clone()) for k, v in blk.params.items()))

@@ -392,7 +392,8 @@ def gen_block_step(is_llama, tag, wbits, abits, group, lwc, let, T=16, randomize
 # G4: learned-parameter trajectory, 2 layers x 4 samples x 2 epochs
 # --------------------------------------------------------------------------------------
 def gen_trajectory(is_llama, tag, wbits, abits, group, lwc, let, aug_loss=False,
-                   let_lr=5e-3, lwc_lr=1e-2, alpha=0.5, T=16, nsamples=4, epochs=2, n_layers=2, cfg_over=None):
+                   let_lr=5e-3, lwc_lr=1e-2, alpha=0.5, T=16, nsamples=4, epochs=2, n_layers=2, cfg_over=None,
+                   batch_size=1):
     fam = "llama" if is_llama else "opt"
     cfg_dict = dict(LLAMA_TINY if is_llama else OPT_TINY, **(cfg_over or {}))
     cfg = LlamaConfig(**cfg_dict) if is_llama else OPTConfig(**cfg_dict)
@@ -440,13 +441,15 @@ def gen_trajectory(is_llama, tag, wbits, abits, group, lwc, let, aug_loss=False,
         opt = torch.optim.AdamW(
             [{"params": qlayer.let_parameters(True), "lr": let_lr},
              {"params": qlayer.lwc_parameters(), "lr": lwc_lr}], weight_decay=0.0)
+        bs = batch_size
+        mask_b = mask.repeat(bs, 1, 1, 1) if bs > 1 else mask       # quantize/omniquant.py:139-141 (attention_mask_batch)
         for ep in range(epochs):
-            for j in range(nsamples):
+            for j in range(0, nsamples // bs * bs, bs):               # quantize/omniquant.py:214-219
                 qlayer.smooth_and_quant_temporary()
-                out = fwd(qlayer, quant_inps[j:j + 1], mask, pos, is_llama)
-                loss = loss_func(fp_inps[j:j + 1], out)
+                out = fwd(qlayer, quant_inps[j:j + bs], mask_b, pos, is_llama)
+                loss = loss_func(fp_inps[j:j + bs], out)
                 if aug_loss:
-                    loss = loss + loss_func(fp_inps_2[j:j + 1], out)
+                    loss = loss + loss_func(fp_inps_2[j:j + bs], out)
                 losses.append(float(loss))
                 opt.zero_grad()
                 loss.backward()
@@ -475,7 +478,7 @@ def gen_trajectory(is_llama, tag, wbits, abits, group, lwc, let, aug_loss=False,
     arrays["norms"] = np.asarray(norms, np.float64)
     meta = dict(family=fam, wbits=wbits, abits=abits, group_size=group, lwc=lwc, let=let, aug_loss=aug_loss,
                 let_lr=let_lr, lwc_lr=lwc_lr, alpha=alpha, T=T, nsamples=nsamples, epochs=epochs,
-                n_layers=n_layers, config=cfg_dict, layer_prefix=prefix)
+                n_layers=n_layers, config=cfg_dict, layer_prefix=prefix, batch_size=batch_size)
     save(f"g4_traj_{fam}_{tag}.npz", arrays, meta)
 
 
@@ -549,7 +552,17 @@ def gen_round2():
     gen_block_step(True, "hd128_w4a4_lwc_let", 4, 4, None, True, True, T=256, cfg_over=hd128, save_tmp=False)
 
 
+def gen_round2b():
+    """--batch_size 2 (quantize/omniquant.py:139-141,214-219: two samples per step, the mask repeated per sample, the MSE
+    a mean over both): one LLaMA W4A4 + LET and one OPT W4A16 trajectory."""
+    gen_trajectory(True, "w4a4_lwc_let_bs2", 4, 4, None, True, True, batch_size=2)
+    gen_trajectory(False, "w4a16_lwc_bs2", 4, 16, None, True, False, batch_size=2)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "round2b":
+        gen_round2b()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "act_stats":
         gen_act_stats()
         sys.exit(0)
@@ -572,3 +585,4 @@ if __name__ == "__main__":
     gen_trajectory(False, "w4a4_lwc_let", 4, 4, None, True, True)
     gen_act_stats()
     gen_round2()
+    gen_round2b()

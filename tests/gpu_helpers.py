@@ -23,7 +23,7 @@ def make_args(meta):
                         let=meta["let"], net=meta["family"], alpha=meta.get("alpha", 0.5),
                         aug_loss=meta.get("aug_loss", False), epochs=meta.get("epochs", 1),
                         let_lr=meta.get("let_lr", 5e-3), lwc_lr=meta.get("lwc_lr", 1e-2),
-                        nsamples=meta.get("nsamples", 1))
+                        nsamples=meta.get("nsamples", 1), batch_size=meta.get("batch_size", 1))
 
 
 def make_cfg(meta):

@@ -128,7 +128,8 @@ def test_trajectory(fname):
     sh = {k[len("act_shifts."):]: T(v) for k, v in g.items() if k.startswith("act_shifts.")}
     res = R.calibrate(m["family"], m["config"], layers, _spec(m), T(g["inps"]), T(g["mask"]),
                       torch.from_numpy(g["position_ids"]), sc, sh, epochs=m["epochs"], let_lr=m["let_lr"],
-                      lwc_lr=m["lwc_lr"], alpha=m["alpha"], aug_loss=m["aug_loss"], prefix=m["layer_prefix"])
+                      lwc_lr=m["lwc_lr"], alpha=m["alpha"], aug_loss=m["aug_loss"], prefix=m["layer_prefix"],
+                      batch_size=m.get("batch_size", 1))
     close(res["losses"], g["losses"], rtol=2e-3, what="losses")
     close(res["norms"], g["norms"], rtol=2e-2, what="norms")
     for i in range(m["n_layers"]):
