@@ -46,6 +46,54 @@ def test_block_step_bf16_sanity(fname):
     assert e["cos"]["fc1_smooth_scale"] > 0.99 and e["cos"]["fc1_smooth_shift"] > 0.98, e["cos"]
 
 
+def test_production_kernels_batch_of_two_equals_mean_of_two_single_steps():
+    """--batch_size 2 through the PRODUCTION kernels (bf16, stacked q|k|v and gate|up GEMMs, fused RoPE -> head quant, fused
+    causal attention, fused silu.up -> quant) on the head_dim-128 / T-256 W4A4 + LET block: every per-token / per-head
+    quantiser, RoPE position and causal mask acts per sample, so the loss of a two-sample step is the mean of the two
+    single-sample losses and every gradient the mean of the two single-sample gradients -- up to bf16 summation noise in
+    the weight-gradient GEMMs (contraction over 512 instead of 2 x 256 tokens)."""
+    from conftest import load_golden
+    from omniquant_amd.calibrate import register_let_parameters
+    fname = "g3_step_llama_hd128_w4a4_lwc_let.npz"
+    g, meta = load_golden(fname)
+    x1, t1 = T(g["x"], DEV, torch.bfloat16), T(g["target"], DEV, torch.bfloat16)
+    x2 = torch.roll(x1, shifts=37, dims=1) * 0.75              # a second, different sample
+    t2 = torch.roll(t1, shifts=37, dims=1) * 0.75
+    mask = T(g["mask"], DEV)
+    pos = torch.from_numpy(g["position_ids"]).to(DEV)
+
+    def step(x, tgt):
+        q, cfg, args = build_block(g, meta, "w.", DEV, torch.bfloat16)
+        q.set_quant_state(weight_quant=False, act_quant=True)
+        q.let = meta["let"]
+        sc = {k[len("act_scales."):]: T(v) for k, v in g.items() if k.startswith("act_scales.")}
+        sh = {k[len("act_shifts."):]: T(v) for k, v in g.items() if k.startswith("act_shifts.")}
+        register_let_parameters(q, meta["family"], sc, sh, meta["alpha"], 0, DEV)
+        with torch.no_grad():
+            for n, p in q.named_parameters():
+                p.data = T(g["p0." + n], DEV).reshape(p.shape)
+        q.smooth_and_quant_temporary()
+        out = q(x, attention_mask=mask.expand(x.shape[0], -1, -1, -1).contiguous(), position_ids=pos)[0]
+        loss = torch.nn.functional.mse_loss(tgt.float(), out.float())
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {n: p.grad.detach().double().cpu().reshape(-1) for n, p in q.named_parameters()}, out.detach().float()
+
+    l1, g1, o1 = step(x1, t1)
+    l2, g2, o2 = step(x2, t2)
+    lb, gb, ob = step(torch.cat([x1, x2]), torch.cat([t1, t2]))
+    assert torch.equal(ob[0], o1[0]) and torch.equal(ob[1], o2[0])          # the forward is per sample, bit for bit
+    assert abs(lb - 0.5 * (l1 + l2)) <= 1e-5 * abs(lb)
+    bad = []
+    for n in gb:
+        want = 0.5 * (g1[n] + g2[n])
+        cos = float(torch.dot(gb[n], want) / (gb[n].norm() * want.norm() + 1e-300))
+        l2e = float((gb[n] - want).norm() / (want.norm() + 1e-300))
+        if not (cos >= 0.999 and l2e <= 0.05):
+            bad.append((n, round(cos, 5), round(l2e, 4)))
+    assert not bad, bad
+
+
 def test_block_step_bf16_production_kernels_vs_reference():
     """The production kernels (bf16 MFMA p3 GEMM incl. its causal modes, fused causal attention forward/backward, bf16
     quantiser instantiations) inside ONE reference-pinned sample-step: the head_dim-128 / T-256 W4A4 + LET fixture.
