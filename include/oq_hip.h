@@ -114,6 +114,19 @@ int oq_gemm(const void* a, const void* bm, void* c, const float* bias, const voi
             int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
             int64_t sc_o, int64_t sc_i, int tri_mode, void* stream);
 
+/* oq_gemm with a caller-owned workspace.  oq_gemm_workspace() gives the number of bytes that lets the kernel split the
+ * contraction of this problem (0: nothing to gain, oq_gemm_ws then behaves exactly like oq_gemm).  Launches whose tile count is
+ * a little more than a whole number of rounds of the 256 CUs (LLaMA-2-13B: N = 5120 -> 320 tiles of 256 x 128 = 1.25 rounds)
+ * are run as S x tiles work items over 1/S of the contraction each, writing fp32 partial outputs [S][M][N] into the
+ * workspace; a second launch adds the parts in index order and applies alpha, bias, addend and the output rounding
+ * (deterministic; not bit-identical to the unsplit launch, whose accumulation order it changes). */
+int64_t oq_gemm_workspace(int64_t M, int64_t N, int64_t K, int in_dtype, int64_t batch, int tri_mode);
+int oq_gemm_ws(const void* a, const void* bm, void* c, const float* bias, const void* addend,
+               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+               int a_kc, int b_kc, int in_dtype, int out_dtype, float alpha,
+               int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
+               int64_t sc_o, int64_t sc_i, int tri_mode, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* column sums: out[n] = sum_m x[m,n]  (bias gradients).  out f32, overwritten.  Deterministic (slab partials in the
  * workspace, added in slab order; no atomics).  cols % 8 == 0. */
 int64_t oq_colsum_workspace(int64_t rows, int64_t cols);

@@ -24,6 +24,8 @@ SIGNATURES = {
                          _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_gemm": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
+    "oq_gemm_ws": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
+                _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _vp],
     "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp],
     "oq_norm_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "oq_norm_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
@@ -87,7 +89,7 @@ SIGNATURES["oq_fakequant_bwd_multi"] = [_vp, _i32, _vp]
 # functions returning a size instead of an error code
 SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64],
               "oq_attn_supported": [_i32, _i64, _i32, _i32], "oq_act_stats_workspace": [_i64, _i64],
-              "oq_colsum_workspace": [_i64, _i64], "oq_rope_quant_supported": [_i32, _i32],
+              "oq_colsum_workspace": [_i64, _i64], "oq_gemm_workspace": [_i64, _i64, _i64, _i32, _i64, _i32], "oq_rope_quant_supported": [_i32, _i32],
               "oq_norm_quant_supported": [_i32, _i64], "oq_norm_quant_bwd_workspace": [_i64, _i64]}
 
 _lib = None

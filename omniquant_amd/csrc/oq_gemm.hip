@@ -52,6 +52,8 @@ struct GemmP {
     float alpha;
     int64_t batch_i, sa_o, sa_i, sb_o, sb_i, sc_o, sc_i;
     int tiles_n, tiles_m, nmajor, tri;
+    int splitk, tiles_real;  // gemm_bf16_p3_kernel: contraction split into `splitk` parts (ids = part * tiles_real + tile), fp32
+                             // partial tiles go to c + part * M * N (c = the workspace); a reduce launch finishes the output
     int blk48;               // gemm_bf16_p3_kernel: strip-ordered tile ids, ~4 x 8-tile blocks per XCD round (see the kernel)
     int epi_lds;             // gemm_bf16_p3_kernel: store the output tile through LDS in whole 128-byte lines
 };
@@ -399,6 +401,8 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
         const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
+    int part = 0;
+    if (p.splitk > 1) { part = tile / p.tiles_real; tile -= part * p.tiles_real; }
     int64_t m0, n0;
     if (p.blk48) {
         // tiles are numbered strip by strip (a strip = 8 n-tiles wide, the last one narrower), m-major inside a strip: ANY 32
@@ -416,7 +420,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
     const int64_t bo = blockIdx.z / p.batch_i, bi = blockIdx.z % p.batch_i;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.a) + bo * p.sa_o + bi * p.sa_i;
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.b) + bo * p.sb_o + bi * p.sb_i;
-    TOUT* C = reinterpret_cast<TOUT*>(p.c) + bo * p.sc_o + bi * p.sc_i;
+    TOUT* C = reinterpret_cast<TOUT*>(p.c) + bo * p.sc_o + bi * p.sc_i + (int64_t)part * p.M * p.N;
 
     // LDS-DMA pieces of this wave: A pieces wid + 8q (q < 4), B pieces wid + 8q (q < 2)
     const bf16_t* ga[4];
@@ -442,7 +446,12 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
     if (p.tri == 1 && n0 >= m0 + P3_BM) return;            // causal: tile entirely above the diagonal
     int64_t kend = p.K;
     if (p.tri == 2 && m0 + P3_BM < kend) kend = m0 + P3_BM;
-    const int t0 = p.tri == 3 ? (int)(m0 / BK) : 0;
+    int t0 = p.tri == 3 ? (int)(m0 / BK) : 0;
+    if (p.splitk > 1) {                                    // this part's slice of the contraction
+        const int64_t kpart = p.K / p.splitk;
+        t0 = (int)(part * kpart / BK);
+        kend = (part + 1) * kpart;
+    }
     const int nt = (int)(kend / BK) - t0;                  // K-tiles of this tile's contraction range
     if (t0) {
 #pragma unroll
@@ -995,9 +1004,113 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmP p) {
             }
 }
 
+thread_local int g_splitk_request = 1;       // set by oq_gemm_ws around its call of the launcher
+
+// ---- split contraction: out = alpha * sum_s ws[s] + bias + addend, parts added in index order (deterministic) ------------
+template <typename TOUT>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* ws, int S, int64_t M, int64_t N, TOUT* c, int64_t ldc,
+                                                            const float* bias, const TOUT* addend, float alpha) {
+    const int64_t nv = N / 8, total = M * nv;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = v / nv, n = (v - m * nv) * 8;
+        float acc[8];
+        Vec8<float>::load(ws + m * N + n, acc);
+        for (int s = 1; s < S; ++s) {
+            float t[8];
+            Vec8<float>::load(ws + ((int64_t)s * M + m) * N + n, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += t[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] *= alpha;
+            if (bias) acc[i] += bias[n + i];
+        }
+        if (addend) {
+            float a[8];
+            Vec8<TOUT>::load(addend + m * ldc + n, a);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += a[i];
+        }
+        Vec8<TOUT>::store(c + m * ldc + n, acc);
+    }
+}
+
+// How many parts the contraction of a bf16 problem is worth splitting into (1 = not at all): launches whose tile count is a
+// little more than a whole number of rounds of the 256 CUs (LLaMA-2-13B: N = 5120 -> 320 tiles = 1.25 rounds of 216-432 K-tiles)
+// run the ragged round at full length; S parts give ceil(S * tiles / 256) rounds of 1/S the length, plus per-tile fixed costs
+// (~8 K-tiles' worth each, tools/gemm_stamps.hip) and one pass over S fp32 partial outputs.
+int splitk_parts(int64_t M, int64_t N, int64_t K, int64_t batch, int tri_mode) {
+    if (dbg_env_i("OQ_GEMM_SPLITK", 1) == 0 || tri_mode != 0 || batch != 1) return 1;
+    if (dbg_env_i("OQ_GEMM_NO_P3", 0) || dbg_env_i("OQ_GEMM_PERSIST", 2) == 1) return 1;      // only the 256x128 kernel splits
+    if (K % BK != 0 || M % 8 != 0 || N % 8 != 0 || M < 128 || N < 128) return 1;
+    const int64_t tiles = ((M + P3_BM - 1) / P3_BM) * ((N + P3_BN - 1) / P3_BN), nt = K / BK;
+    // costs in K-tile times (~0.8 us): 12 per tile for its fixed costs incl. the larger fp32 store, and the reduce pass at ~2.7 TB/s
+    // effective; calibrated on the three 13B launches (tools/ab_gemm_13b.py: K = 27648 +25 %, 15360 +8 %, 13824 -2 % -> not split)
+    const double fixed = 12.0;
+    auto rounds = [&](int64_t t) { return (double)((t + 255) / 256); };
+    const double base = rounds(tiles) * (nt + fixed);
+    int best = 1;
+    double best_cost = base * 0.88;                      // at least 12 % better by this model, or not at all
+    for (int S = 2; S <= 4; ++S) {
+        if (nt % S != 0 || nt / S < 32) continue;
+        const double reduce = 1.5 * ((double)(S + 1) * M * N * 4.0 / 4.0e12) / 0.85e-6;
+        const double cost = rounds(tiles * S) * ((double)nt / S + fixed) + reduce;
+        if (cost < best_cost) { best_cost = cost; best = S; }
+    }
+    return best;
+}
+
 }  // namespace
 
+extern "C" int64_t oq_gemm_workspace(int64_t M, int64_t N, int64_t K, int in_dtype, int64_t batch, int tri_mode) {
+    if (in_dtype != OQ_BF16 || M <= 0 || N <= 0 || K <= 0) return 0;
+    const int S = splitk_parts(M, N, K, batch, tri_mode);
+    return S > 1 ? (int64_t)S * M * N * 4 : 0;
+}
+
+static int oq_gemm_impl(const void* a, const void* bm, void* c, const float* bias, const void* addend, int64_t M, int64_t N,
+                        int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
+                        float alpha, int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
+                        int64_t sc_o, int64_t sc_i, int tri_mode, void* stream);
+
+extern "C" int oq_gemm_ws(const void* a, const void* bm, void* c, const float* bias, const void* addend, int64_t M, int64_t N,
+                          int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
+                          float alpha, int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
+                          int64_t sc_o, int64_t sc_i, int tri_mode, void* workspace, int64_t workspace_bytes, void* stream) {
+    const int S = (in_dtype == OQ_BF16 && workspace && M > 0 && N > 0 && K > 0) ? splitk_parts(M, N, K, batch_o * batch_i, tri_mode) : 1;
+    if (S <= 1 || workspace_bytes < (int64_t)S * M * N * 4 || !oq_aligned16(workspace) || ldc % 8 != 0 || !oq_aligned16(c) ||
+        (addend && !oq_aligned16(addend)) || (out_dtype != OQ_F32 && out_dtype != OQ_BF16))
+        return oq_gemm_impl(a, bm, c, bias, addend, M, N, K, lda, ldb, ldc, a_kc, b_kc, in_dtype, out_dtype, alpha, batch_o, batch_i,
+                            sa_o, sa_i, sb_o, sb_i, sc_o, sc_i, tri_mode, stream);
+    // S launches' worth of tiles in ONE launch: fp32 partial outputs [S][M][N] in the workspace, then the reduce
+    g_splitk_request = S;
+    const int rc = oq_gemm_impl(a, bm, workspace, nullptr, nullptr, M, N, K, lda, ldb, N, a_kc, b_kc, in_dtype, OQ_F32, 1.0f, 1, 1,
+                                0, 0, 0, 0, 0, 0, 0, stream);
+    g_splitk_request = 1;
+    if (rc != OQ_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nvec = M * (N / 8);
+    const unsigned grid = (unsigned)(nvec / 256 + 1 < 4096 ? nvec / 256 + 1 : 4096);
+    if (out_dtype == OQ_F32)
+        hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)workspace, S, M, N, (float*)c, ldc,
+                           bias, (const float*)addend, alpha);
+    else
+        hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)workspace, S, M, N, (bf16_t*)c, ldc,
+                           bias, (const bf16_t*)addend, alpha);
+    OQ_CHECK_LAUNCH("oq_gemm_ws(reduce)");
+    return OQ_OK;
+}
+
 extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias, const void* addend, int64_t M, int64_t N,
+                       int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
+                       float alpha, int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
+                       int64_t sc_o, int64_t sc_i, int tri_mode, void* stream) {
+    return oq_gemm_impl(a, bm, c, bias, addend, M, N, K, lda, ldb, ldc, a_kc, b_kc, in_dtype, out_dtype, alpha, batch_o, batch_i, sa_o,
+                        sa_i, sb_o, sb_i, sc_o, sc_i, tri_mode, stream);
+}
+
+static int oq_gemm_impl(const void* a, const void* bm, void* c, const float* bias, const void* addend, int64_t M, int64_t N,
                        int64_t K,
                        int64_t lda, int64_t ldb, int64_t ldc, int a_kc, int b_kc, int in_dtype, int out_dtype,
                        float alpha, int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o,
@@ -1043,7 +1156,9 @@ extern "C" int oq_gemm(const void* a, const void* bm, void* c, const float* bias
             const int64_t tm3 = (M + P3_BM - 1) / P3_BM, tn3 = (N + P3_BN - 1) / P3_BN;
             p.tiles_n = (int)tn3;
             p.tiles_m = (int)tm3;
-            dim3 grid3((unsigned)(tm3 * tn3), 1, (unsigned)(batch_o * batch_i));
+            p.splitk = g_splitk_request;
+            p.tiles_real = (int)(tm3 * tn3);
+            dim3 grid3((unsigned)(tm3 * tn3 * (p.splitk > 1 ? p.splitk : 1)), 1, (unsigned)(batch_o * batch_i));
             // persistent tile loop: wins where the per-tile pipeline fill dominates (short K, batched attention
             // problems); the plain kernel's leaner main loop wins on the long-K linears (measured, tools/ab_gemm.py)
             const int persist = dbg_env_i("OQ_GEMM_PERSIST", 2);

@@ -291,9 +291,17 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, a_kc, b_kc, bias=None, alpha=1.0, batc
         if not t.is_contiguous():
             raise C.OQError("gemm: non-contiguous buffer")
     es_in, es_out = a.element_size(), c.element_size()
-    C.call("oq_gemm", a.data_ptr() + a_off * es_in, b.data_ptr() + b_off * es_in, c.data_ptr() + c_off * es_out,
-           C.fptr(bias), None if addend is None else addend.data_ptr() + c_off * es_out, M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc), C.dt(a), C.dt(c), float(alpha),
-           batch_o, batch_i, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], int(tri), C.stream())
+    args = (a.data_ptr() + a_off * es_in, b.data_ptr() + b_off * es_in, c.data_ptr() + c_off * es_out,
+            C.fptr(bias), None if addend is None else addend.data_ptr() + c_off * es_out, M, N, K, lda, ldb, ldc, int(a_kc), int(b_kc),
+            C.dt(a), C.dt(c), float(alpha), batch_o, batch_i, sa[0], sa[1], sb[0], sb[1], sc[0], sc[1], int(tri))
+    ws_bytes = C.size_call("oq_gemm_workspace", M, N, K, C.dt(a), batch_o * batch_i, int(tri))
+    if ws_bytes:
+        # a ragged round of long tiles (LLaMA-2-13B's N = 5120 launches): the kernel splits the contraction into S parts and a
+        # second launch adds the fp32 partial outputs it parks in this workspace
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
+        C.call("oq_gemm_ws", *args, ws.data_ptr(), ws_bytes, C.stream())
+    else:
+        C.call("oq_gemm", *args, C.stream())
 
 
 class SiblingGrads:

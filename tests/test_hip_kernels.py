@@ -1,6 +1,7 @@
 """-m gpu parity tests of the individual HIP kernels, called through the C ABI (ctypes), against
 (a) the golden vectors generated from the reference and (b) plain torch float64/float32 restatements."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -154,6 +155,38 @@ def test_gemm_strip_ordered_tiles_and_lds_epilogue_exact(a_kc, b_kc, M, N, K):
     cb = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
     ops.gemm(a, b, cb, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc, b_kc)
     assert torch.equal(cb.cpu().float(), (A @ B.T).bfloat16().float())
+
+
+@pytest.mark.parametrize("a_kc,b_kc,M,N,K", [(True, False, 2048, 5120, 27648), (True, True, 2048, 5120, 15360), (False, False, 2048, 5120, 15360)])
+def test_gemm_split_contraction_exact(a_kc, b_kc, M, N, K):
+    """The LLaMA-2-13B launches with N = 5120 (320 tiles of 256 x 128 = 1.25 rounds of the 256 CUs, 216-432 K-tiles long):
+    oq_gemm_workspace() asks for S x M x N fp32 words and oq_gemm_ws runs S x 320 work items over 1/S of the contraction each,
+    then adds the partial outputs in index order.  Integer-valued operands make every partial sum exact in fp32, so the result
+    must EQUAL the unsplit one and the exact product, with bias and output accumulation, in fp32 and in bf16."""
+    from omniquant_amd import ops, _capi as C
+    assert C.size_call("oq_gemm_workspace", M, N, K, C._DT[torch.bfloat16], 1, 0) >= 3 * M * N * 4
+    assert C.size_call("oq_gemm_workspace", 2048, 4096, 4096, C._DT[torch.bfloat16], 1, 0) == 0      # whole rounds: no split
+    g = torch.Generator().manual_seed(K)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    bias = torch.randint(-5, 6, (N,), generator=g).float().to(DEV)
+    add = torch.randint(-9, 10, (M, N), generator=g).float().to(DEV)
+    a = (A if a_kc else A.T.contiguous()).bfloat16().to(DEV)
+    b = (B if b_kc else B.T.contiguous()).bfloat16().to(DEV)
+    want = A.to(DEV) @ B.to(DEV).T + bias[None, :] + add               # exact: |sum| < 2^24
+    c = add.clone()
+    ops.gemm(a, b, c, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc, b_kc, bias=bias, addend=c)
+    assert torch.equal(c, want)
+    os.environ["OQ_GEMM_SPLITK"] = "0"
+    try:
+        c0 = add.clone()
+        ops.gemm(a, b, c0, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc, b_kc, bias=bias, addend=c0)
+    finally:
+        del os.environ["OQ_GEMM_SPLITK"]
+    assert torch.equal(c0, want)
+    cb = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a, b, cb, M, N, K, K if a_kc else M, K if b_kc else N, N, a_kc, b_kc, alpha=0.5)
+    assert torch.equal(cb.float(), (0.5 * (A.to(DEV) @ B.to(DEV).T)).bfloat16().float())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
