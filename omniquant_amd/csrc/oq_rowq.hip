@@ -1060,10 +1060,10 @@ static bool letq_fwd_eligible(const FQ& p) {
 int oq_letq_fwd_multi(const FQ* ps, int n, int w_dtype, int y_dtype, void* stream) {
     if (n < 2 || n > OQ_WQ_MAX || env_i("OQ_WQ_MULTI", 1) == 0) return 1;
     const int ch = letq_fwd_eligible(ps[0]) ? letq_ch(ps[0].cols) : 0;
-    if (ch != 2) return 1;
+    if (ch != 2 && ch != 3) return 1;
     for (int i = 0; i < n; ++i)
         if (!letq_fwd_eligible(ps[i]) || ps[i].cols != ps[0].cols || ps[i].nbits != ps[0].nbits) return 1;
-    const int rgt = env_i("OQ_LETQ_FWD_RG", 2) == 2 ? 2 : 4;
+    const int rgt = (ch == 2 && env_i("OQ_LETQ_FWD_RG", 2) == 2) ? 2 : 4;      // rows of 4097..6144 elements: groups of 4 (as the single launch)
     MultiFQ m{};
     m.n = n;
     const int64_t cap = (int64_t)n_cus() * env_i("OQ_LETQ_FWD_WGS", 8);
@@ -1080,7 +1080,8 @@ int oq_letq_fwd_multi(const FQ* ps, int n, int w_dtype, int y_dtype, void* strea
     hipStream_t st = (hipStream_t)stream;
 #define LQ_FWD_MULTI(TIN, TOUT)                                                                              \
     do {                                                                                                     \
-        if (rgt == 2) hipLaunchKernelGGL((letq_fwd_multi_kernel<TIN, TOUT, 2, 2>), grid, dim3(256), 0, st, m); \
+        if (ch == 3) hipLaunchKernelGGL((letq_fwd_multi_kernel<TIN, TOUT, 3, 4>), grid, dim3(256), 0, st, m);   \
+        else if (rgt == 2) hipLaunchKernelGGL((letq_fwd_multi_kernel<TIN, TOUT, 2, 2>), grid, dim3(256), 0, st, m); \
         else hipLaunchKernelGGL((letq_fwd_multi_kernel<TIN, TOUT, 2, 4>), grid, dim3(256), 0, st, m);        \
     } while (0)
     switch (w_dtype * 3 + y_dtype) {
@@ -1105,7 +1106,7 @@ static bool letq_bwd_eligible(const FQ& p) {
 int oq_letq_bwd_multi(FQ* ps, int n, int w_dtype, int g_dtype, const int64_t* workspace_floats, int64_t* parts, void* stream) {
     if (n < 2 || n > OQ_WQ_MAX || env_i("OQ_WQ_MULTI", 1) == 0) return 1;
     const int ch = letq_bwd_eligible(ps[0]) ? letq_ch(ps[0].cols) : 0;
-    if (ch != 2) return 1;
+    if (ch != 2 && ch != 3) return 1;
     for (int i = 0; i < n; ++i)
         if (!letq_bwd_eligible(ps[i]) || ps[i].cols != ps[0].cols || ps[i].nbits != ps[0].nbits) return 1;
     MultiFQ m{};
@@ -1130,7 +1131,11 @@ int oq_letq_bwd_multi(FQ* ps, int n, int w_dtype, int g_dtype, const int64_t* wo
     m.start[n] = (int)tot;
     const dim3 grid((unsigned)tot);
     hipStream_t st = (hipStream_t)stream;
-#define LQ_BWD_MULTI(TIN, TG) hipLaunchKernelGGL((letq_bwd_multi_kernel<TIN, TG, 2>), grid, dim3(256), 0, st, m)
+#define LQ_BWD_MULTI(TIN, TG)                                                                              \
+    do {                                                                                                   \
+        if (ch == 3) hipLaunchKernelGGL((letq_bwd_multi_kernel<TIN, TG, 3>), grid, dim3(256), 0, st, m);     \
+        else hipLaunchKernelGGL((letq_bwd_multi_kernel<TIN, TG, 2>), grid, dim3(256), 0, st, m);            \
+    } while (0)
     switch (w_dtype * 3 + g_dtype) {
         case OQ_F32 * 3 + OQ_F32: LQ_BWD_MULTI(float, float); break;
         case OQ_F32 * 3 + OQ_BF16: LQ_BWD_MULTI(float, bf16_t); break;

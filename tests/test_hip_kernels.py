@@ -437,14 +437,15 @@ def test_colsum_bias_gradient_kernels(direct, monkeypatch):
 
 @pytest.mark.parametrize("n_back", [4, 3])
 @pytest.mark.parametrize("routed", [True, False])
-def test_weight_quant_batch_matches_single_launches(n_back, routed):
+@pytest.mark.parametrize("cols", [4096, 5120])
+def test_weight_quant_batch_matches_single_launches(n_back, routed, cols):
     """ops.WeightQuantBatch: the LET weights of one shape quantised in ONE multi-matrix launch per direction
     (oq_fakequant_fwd_multi / oq_fakequant_bwd_multi) give bit-identical outputs and gradients to one launch per matrix;
     a sibling whose gradient never arrives (n_back = 3) does not leave the others unlaunched.  routed: the gradients go to
     the optimiser's sinks / collector (the engine's case, backward launches are merged too) or back to autograd (then the
     backward launches stay separate: AccumulateGrad copies what it is handed at once)."""
     from omniquant_amd import ops
-    rows, cols = 512, 4096
+    rows = 512                     # cols: 4096 (LLaMA-7B: 2 chunks per lane) and 5120 (LLaMA-2-13B: 3 chunks per lane)
     modes = [dict(rd=True), dict(rm=True), dict(rd=True), dict()]          # q, k, v, o
 
     class Collector:
