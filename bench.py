@@ -258,6 +258,33 @@ def end_to_end(name, rank, world, dev, dist, n_samples, blocks_per_rank, chunk):
                          "pass, hipGraph capture, sample-steps, fold, propagate, final parameter gather")
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n, argv, port=None, python=None):
+    """The `torch.distributed.run` command line of an N-rank run of this script on one node (rendezvous on 127.0.0.1)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n, argv):
+    """Runs launch_command() as a child process group, passes its stdout / stderr through and returns its exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this image
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(launch_command(n, argv), env=env, cwd=ROOT)
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -274,15 +301,32 @@ def main():
     ap.add_argument("--boundary-chunk", type=int, default=4, help="samples per boundary message of the teacher pre-pass")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one fresh process per GPU and relay rank 0's JSON line.  Nothing in this
+        # process has touched the GPU (no HIP call, no torch.cuda query), and the children are started, never exec'd into.
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {a.gpus}` "
+                         f"(it launches its own ranks) or under torch.distributed.run with --nproc-per-node {a.gpus}")
     dist = None
+    if os.environ.get("OQ_BENCH_LAUNCH_ONLY"):      # tests/test_host_logic_cpu.py: rendezvous of the ranks only (gloo, no GPU)
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, local_rank))
+        if rank == 0:
+            print(json.dumps({"launch_only": True, "n_gpus": a.gpus, "world": world, "ranks": seen}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     from omniquant_amd import _capi

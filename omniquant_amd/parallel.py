@@ -59,10 +59,19 @@ def pipeline_teacher_boundaries(inps, lo, hi, teacher_chunk_forward, group=None,
             recv_req.wait()
             if c + 1 < len(bounds):
                 recv_req = dist.irecv(rbuf[c + 1], src=rank - 1, group=group)     # next message lands under this compute
+            if rbuf[c].dtype != bank.dtype or tuple(rbuf[c].shape) != tuple(bank[a:b].shape):
+                raise RuntimeError("boundary message does not have the bank's dtype / shape")
             bank[a:b].copy_(rbuf[c])
             rbuf[c] = None
         if rank < world - 1:
-            out = teacher_chunk_forward(lo, hi, bank[a:b].clone()).contiguous()
+            out = teacher_chunk_forward(lo, hi, bank[a:b].clone())
+            # the wire format is the BANK's dtype and shape: the receiver's buffer was allocated from `inps`, and neither
+            # RCCL nor gloo checks that the two sides agree (a bf16 message landing in an fp16 buffer would be reinterpreted
+            # bit for bit).  A teacher that computes in another dtype is converted here, once per message.
+            if tuple(out.shape) != (b - a,) + tuple(inps.shape[1:]):
+                raise RuntimeError(f"teacher_chunk_forward returned shape {tuple(out.shape)} for a message of "
+                                   f"{(b - a,) + tuple(inps.shape[1:])}")
+            out = out.to(inps.dtype).contiguous()
             msg = out.cpu() if staged else out
             pending.append((dist.isend(msg, dst=rank + 1, group=group), msg))       # keep the buffer alive until sent
     for req, _ in pending:

@@ -54,3 +54,31 @@ def test_shard_bounds_cover_exactly_once():
                 lo, hi = shard_bounds(n, w, r)
                 seen += list(range(lo, hi))
             assert seen == list(range(n))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (N > 1, no WORLD_SIZE) must start N fresh rank processes itself -- torch.distributed.run on
+    127.0.0.1 -- before anything touches a GPU, relay rank 0's single JSON line and return the children's exit code."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"], port=29511, python="py")
+    assert cmd[:3] == ["py", "-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5:] == [os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OQ_BENCH_LAUNCH_ONLY"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and lines[0]["world"] == 2 and sorted(map(tuple, lines[0]["ranks"])) == [(0, 0), (1, 1)]
+    # a world size that does not match --gpus is refused with a message, not an assert
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29512")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True,
+                        timeout=300)
+    assert r2.returncode != 0 and "--gpus 2 but WORLD_SIZE=3" in r2.stderr

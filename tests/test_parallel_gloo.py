@@ -128,3 +128,38 @@ def test_chunked_teacher_pipeline_three_ranks_gloo(chunk):
     n_msg = 1 if (chunk is None or chunk >= 7) else -(-7 // chunk)
     assert len(outs[0]["calls"]) == n_msg and len(outs[1]["calls"]) == n_msg and outs[2]["calls"] == []
     assert sum(outs[0]["calls"]) == 7
+
+
+def _dtype_worker(rank, world, initfile, outdir, tdt):
+    sys.path.insert(0, ROOT)
+    from omniquant_amd.parallel import pipeline_teacher_boundaries, shard_bounds
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(3)
+    inps = torch.randn(5, 4, 8, generator=g).half()        # fp16 bank, as the reference's Catcher records it
+    tdtype = getattr(torch, tdt)
+
+    def teacher(lo, hi, bank):                             # computes (and returns) in ITS dtype, like hip_callables' teacher
+        bank = bank.to(tdtype)
+        for i in range(lo, hi):
+            bank = bank * 1.5 + (i + 1)
+        return bank
+
+    lo, hi = shard_bounds(2, world, rank)
+    bank = pipeline_teacher_boundaries(inps, lo, hi, teacher, None, 2)
+    torch.save({"bank": bank}, os.path.join(outdir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tdt", ["bfloat16", "float32"])
+def test_boundary_messages_travel_in_the_bank_dtype(tdt):
+    """An fp16 bank with a teacher that computes in bf16 / f32: the message is converted to the bank's dtype before it is
+    sent (the receive buffer has the bank's dtype and neither backend checks), so rank 1 gets VALUES, not reinterpreted bits."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_dtype_worker, args=(2, os.path.join(d, "init"), d, tdt), nprocs=2, join=True)
+        got = torch.load(os.path.join(d, "r1.pt"), weights_only=True)["bank"]
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 4, 8, generator=g).half()
+    want = (x.to(getattr(torch, tdt)) * 1.5 + 1).half()
+    assert got.dtype == torch.float16 and torch.equal(got, want)
