@@ -127,6 +127,20 @@ int oq_gemm_ws(const void* a, const void* bm, void* c, const float* bias, const 
                int64_t batch_o, int64_t batch_i, int64_t sa_o, int64_t sa_i, int64_t sb_o, int64_t sb_i,
                int64_t sc_o, int64_t sc_i, int tri_mode, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Integer-exact fprop of the fake-quant Linear (quantize/int_linear.py:59-62 with both operands on
+ * UniformAffineQuantizer grids, quantize/quantizer.py:84-105):
+ *   c[m][n] = a_scale[m] * b_scale[n] * sum_k (qa[m][k] - a_zp[m]) * (qb[n][k] - b_zp[n]) + bias[n] (+ addend[m][n])
+ * a_codes [M][lda], b_codes [N][ldb]: int8, the grid code minus 2^(bits-1) (what the quantiser entry points write into their
+ * `codes` output; `*_csum[r]` = sum over k of the STORED codes of row r, as float).  The contraction runs on
+ * v_mfma_i32_16x16x64_i8 into int32 (exact); scales, the three zero-point terms, bias and addend are applied in fp32 in the
+ * epilogue.  out_dtype OQ_F32 / OQ_BF16; addend has the output's dtype and leading dimension.  Fast path: K % 128 == 0,
+ * N % 8 == 0, N >= 128, 16-byte aligned rows; anything else runs a plain one-thread-per-output kernel (same arithmetic). */
+int oq_gemm_i8(const void* a_codes, const void* b_codes, void* c, const float* bias, const void* addend,
+               const float* a_scale, const float* a_zp, const float* a_csum,
+               const float* b_scale, const float* b_zp, const float* b_csum,
+               int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+               int a_bits, int b_bits, int out_dtype, void* stream);
+
 /* column sums: out[n] = sum_m x[m,n]  (bias gradients).  out f32, overwritten.  Deterministic (slab partials in the
  * workspace, added in slab order; no atomics).  cols % 8 == 0. */
 int64_t oq_colsum_workspace(int64_t rows, int64_t cols);

@@ -26,6 +26,7 @@ SIGNATURES = {
                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "oq_gemm_ws": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _vp],
+    "oq_gemm_i8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
     "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp],
     "oq_norm_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "oq_norm_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],

@@ -304,6 +304,41 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, a_kc, b_kc, bias=None, alpha=1.0, batc
         C.call("oq_gemm", *args, C.stream())
 
 
+class IntCodes:
+    """Integer side of a fake-quantised tensor, written by the quantiser kernels next to their bf16 / f32 output:
+    codes [rows, cols] int8 = grid code - 2^(nbits-1); scale, zp [rows] (the quantiser's scale / rounded zero-point);
+    csum [rows] = sum of the stored codes of the row (float, exact).  With it  dequant[r][k] = (codes[r][k] + 2^(nbits-1) -
+    zp[r]) * scale[r]  exactly, and a Linear whose two operands carry IntCodes runs its fprop on the int8 MFMA (gemm_i8)."""
+    __slots__ = ("codes", "scale", "zp", "csum", "nbits")
+
+    def __init__(self, codes, scale, zp, csum, nbits):
+        self.codes, self.scale, self.zp, self.csum, self.nbits = codes, scale, zp, csum, int(nbits)
+
+    def rows(self, lo, hi):
+        """The same for the row block [lo, hi) (sibling weights stacked in one buffer)."""
+        return IntCodes(self.codes[lo:hi], self.scale[lo:hi], self.zp[lo:hi], self.csum[lo:hi], self.nbits)
+
+
+def gemm_i8(a, b, c, bias=None, addend=None):
+    """c[M, N] = dequant(a)[M, K] @ dequant(b)[N, K]^T + bias (+ addend), contracted exactly on the int8 MFMA (oq_gemm_i8).
+    a, b: IntCodes; c: preallocated [M, N] float32 / bfloat16 GPU tensor."""
+    M, K = a.codes.shape
+    N = b.codes.shape[0]
+    if b.codes.shape[1] != K or tuple(c.shape) != (M, N):
+        raise C.OQError(f"gemm_i8: shapes a {tuple(a.codes.shape)} b {tuple(b.codes.shape)} c {tuple(c.shape)}")
+    for t in (a.codes, b.codes):
+        if t.dtype != torch.int8 or not t.is_cuda or not t.is_contiguous():
+            raise C.OQError("gemm_i8: codes must be contiguous int8 GPU tensors; there is no CPU fallback")
+    for v, n in ((a.scale, M), (a.zp, M), (a.csum, M), (b.scale, N), (b.zp, N), (b.csum, N)):
+        if v.numel() != n or v.dtype != torch.float32:
+            raise C.OQError("gemm_i8: per-row vectors must be float32 with one entry per row")
+    if addend is not None and (addend.dtype != c.dtype or tuple(addend.shape) != (M, N) or not addend.is_contiguous()):
+        raise C.OQError("gemm_i8: addend must be a contiguous tensor of the output's dtype and shape")
+    C.call("oq_gemm_i8", C.ptr(a.codes), C.ptr(b.codes), C.ptr(c), C.fptr(bias), C.ptr(addend),
+           C.fptr(a.scale), C.fptr(a.zp), C.fptr(a.csum), C.fptr(b.scale), C.fptr(b.zp), C.fptr(b.csum),
+           M, N, K, K, K, N, a.nbits, b.nbits, C.dt(c), C.stream())
+
+
 class SiblingGrads:
     """Side channel for the input gradient of SIBLING consumers of one tensor (q/k/v projections; gate/up): the first
     consumer whose backward runs returns its dL/dx to autograd as usual, the others park theirs here and return None, and
