@@ -49,7 +49,14 @@ int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int
                      const float* col_mul, const float* row_div, const float* row_mul, const float* shift,
                      const float* up, const float* low,
                      void* y, int y_dtype, float* scale, float* zp, float* xmin, float* xmax, float* wshift,
-                     void* stream);
+                     void* codes, float* csum, void* stream);
+/* Integer side channel of the quantiser forwards (optional; `codes` and `csum` both NULL or both given): next to y the
+ * kernels store the GRID CODES of quantize/quantizer.py:93-99 (x_int after the clamp, 0 .. 2^nbits - 1) as int8 [rows, cols]
+ * -- plain codes for nbits <= 7, code - 128 for nbits = 8 -- and per row the sum of the stored codes (float, exact; NaN for a
+ * row whose scale is 0 / NaN, the reference's all-NaN row of quirk Q1).  With scale / zp that is the exact factorisation
+ * y = (code - zp) * scale, which oq_gemm_i8 contracts on the int8 MFMA.  Available for whole-row segments on grids of at
+ * most 8 bits when oq_fakequant_codes_supported(cols, seg, nbits, let) is 1 (let: any of col_mul / row_div / row_mul / shift). */
+int64_t oq_fakequant_codes_supported(int64_t cols, int64_t seg, int nbits, int let);
 
 /* Backward of the above (closed form of the autograd graph the reference builds).
  *   g [rows,cols] (g_dtype) = dL/dy ; g_wshift [rows] = dL/d wshift (optional)
@@ -77,6 +84,7 @@ typedef struct {
     const float *col_mul, *row_div, *row_mul, *shift, *up, *low;
     void* y; int y_dtype;
     float *scale, *zp, *xmin, *xmax, *wshift;
+    void* codes; float* csum;
 } oq_fakequant_fwd_args;
 typedef struct {
     const void* w; int w_dtype; int64_t rows, cols, seg; int nbits, symmetric;
@@ -130,8 +138,8 @@ int oq_gemm_ws(const void* a, const void* bm, void* c, const float* bias, const 
 /* Integer-exact fprop of the fake-quant Linear (quantize/int_linear.py:59-62 with both operands on
  * UniformAffineQuantizer grids, quantize/quantizer.py:84-105):
  *   c[m][n] = a_scale[m] * b_scale[n] * sum_k (qa[m][k] - a_zp[m]) * (qb[n][k] - b_zp[n]) + bias[n] (+ addend[m][n])
- * a_codes [M][lda], b_codes [N][ldb]: int8, the grid code minus 2^(bits-1) (what the quantiser entry points write into their
- * `codes` output; `*_csum[r]` = sum over k of the STORED codes of row r, as float).  The contraction runs on
+ * a_codes [M][lda], b_codes [N][ldb]: int8, the grid codes as the quantiser entry points write them into their `codes`
+ * output (plain codes; code - 128 on 8-bit grids); `*_csum[r]` = sum over k of the STORED codes of row r, as float.  The contraction runs on
  * v_mfma_i32_16x16x64_i8 into int32 (exact); scales, the three zero-point terms, bias and addend are applied in fp32 in the
  * epilogue.  out_dtype OQ_F32 / OQ_BF16; addend has the output's dtype and leading dimension.  Fast path: K % 128 == 0,
  * N % 8 == 0, N >= 128, 16-byte aligned rows; anything else runs a plain one-thread-per-output kernel (same arithmetic). */
@@ -189,10 +197,12 @@ int oq_silu_mul_bwd_2d(const void* gate, const void* up, const void* gy, void* g
  * through a workspace of oq_norm_quant_bwd_workspace(rows, cols) floats (deterministic two-stage reduction). */
 int64_t oq_norm_quant_supported(int dtype, int64_t cols);
 int64_t oq_norm_quant_bwd_workspace(int64_t rows, int64_t cols);
+/* y_dtype / g_dtype: the dtype of y resp. of g, g2, g3, gx_addend and gx -- equal to x's, or OQ_BF16 with an OQ_F32 x (a
+ * hidden state kept in fp32 in front of the 4-bit rounding decision).  codes / csum: see oq_fakequant_fwd. */
 int oq_norm_quant_fwd(const void* x, int dtype, int64_t rows, int64_t cols, const float* w, const float* b, float eps,
-                      int is_layernorm, int nbits, void* y, float* rstd, float* mean, float* scale, float* zp, float* xmin,
-                      float* xmax, void* stream);
-int oq_norm_quant_bwd(const void* x, const void* g, const void* g2, const void* g3, int dtype, int64_t rows, int64_t cols,
+                      int is_layernorm, int nbits, void* y, int y_dtype, float* rstd, float* mean, float* scale, float* zp,
+                      float* xmin, float* xmax, void* codes, float* csum, void* stream);
+int oq_norm_quant_bwd(const void* x, const void* g, const void* g2, const void* g3, int dtype, int g_dtype, int64_t rows, int64_t cols,
                       const float* w, const float* b,
                       const float* rstd, const float* mean, int is_layernorm, int nbits, const float* xmin, const float* xmax,
                       void* gx, float* gw, float* gb, const void* gx_addend, float* workspace, int64_t workspace_floats,
@@ -228,10 +238,12 @@ int oq_qkv_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64_t T, i
  * ld: row stride (elements, multiple of 8, >= cols; 0 = cols) of gate / up and of ggate / gup -- gate | up may be the two
  * column blocks of the ONE buffer a stacked gate/up GEMM writes, and their gradients the column blocks of the buffer the
  * stacked dgrad / wgrad GEMMs read; y and g are always dense [rows, cols]. */
+/* dtype: gate / up; y_dtype / g_dtype: y resp. g, ggate, gup -- equal to dtype, or OQ_BF16 with OQ_F32 gate / up (projection
+ * outputs kept in fp32 in front of the rounding decision).  codes / csum: see oq_fakequant_fwd. */
 int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype, int64_t rows, int64_t cols, int64_t ld, int nbits, void* y,
-                          float* scale, float* zp, float* xmin, float* xmax, void* stream);
-int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int64_t rows, int64_t cols, int64_t ld,
-                          int nbits, const float* xmin, const float* xmax, void* ggate, void* gup, void* stream);
+                          int y_dtype, float* scale, float* zp, float* xmin, float* xmax, void* codes, float* csum, void* stream);
+int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int g_dtype, int64_t rows, int64_t cols,
+                          int64_t ld, int nbits, const float* xmin, const float* xmax, void* ggate, void* gup, void* stream);
 int oq_relu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream);
 int oq_relu_bwd(const void* x, const void* gy, void* gx, int dtype, int64_t n, void* stream);
 int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols, float alpha, const float* mask,

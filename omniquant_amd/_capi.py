@@ -19,7 +19,7 @@ _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_v
 # name -> argtypes, exactly as declared in include/oq_hip.h (tests/test_capi_symbols.py cross-checks the header)
 SIGNATURES = {
     "oq_fakequant_fwd": [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
-                         _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
+                         _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "oq_fakequant_bwd": [_vp, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                          _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_gemm": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
@@ -35,14 +35,14 @@ SIGNATURES = {
     "oq_silu_mul_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp],
     "oq_silu_mul_fwd_2d": [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp],
     "oq_silu_mul_bwd_2d": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _vp],
-    "oq_norm_quant_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "oq_norm_quant_bwd": [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "oq_norm_quant_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "oq_norm_quant_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_rope_quant_fwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_rope_quant_bwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "oq_qkv_rope_quant_fwd": [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_qkv_rope_quant_bwd": [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
-    "oq_silu_mul_quant_fwd": [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp],
-    "oq_silu_mul_quant_bwd": [_vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    "oq_silu_mul_quant_fwd": [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "oq_silu_mul_quant_bwd": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_relu_fwd": [_vp, _vp, _i32, _i64, _vp],
     "oq_relu_bwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_softmax_fwd": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _i64, _i32, _vp],
@@ -72,7 +72,7 @@ class FakeQuantFwdArgs(ctypes.Structure):
     _fields_ = [("w", _vp), ("w_dtype", _i32), ("rows", _i64), ("cols", _i64), ("seg", _i64), ("nbits", _i32),
                 ("symmetric", _i32), ("col_mul", _vp), ("row_div", _vp), ("row_mul", _vp), ("shift", _vp), ("up", _vp),
                 ("low", _vp), ("y", _vp), ("y_dtype", _i32), ("scale", _vp), ("zp", _vp), ("xmin", _vp), ("xmax", _vp),
-                ("wshift", _vp)]
+                ("wshift", _vp), ("codes", _vp), ("csum", _vp)]
 
 
 class FakeQuantBwdArgs(ctypes.Structure):
@@ -91,7 +91,8 @@ SIGNATURES["oq_fakequant_bwd_multi"] = [_vp, _i32, _vp]
 SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64],
               "oq_attn_supported": [_i32, _i64, _i32, _i32], "oq_act_stats_workspace": [_i64, _i64],
               "oq_colsum_workspace": [_i64, _i64], "oq_gemm_workspace": [_i64, _i64, _i64, _i32, _i64, _i32], "oq_rope_quant_supported": [_i32, _i32],
-              "oq_norm_quant_supported": [_i32, _i64], "oq_norm_quant_bwd_workspace": [_i64, _i64]}
+              "oq_norm_quant_supported": [_i32, _i64], "oq_norm_quant_bwd_workspace": [_i64, _i64],
+              "oq_fakequant_codes_supported": [_i64, _i64, _i32, _i32]}
 
 _lib = None
 

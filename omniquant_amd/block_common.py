@@ -109,14 +109,25 @@ class QuantBlockMixin:
                     not any(m.weight_quantizer._identity() for m in group):
                 if group[0] is not nm["q"]:
                     group = sorted(group, key=lambda m: 0 if m is getattr(getattr(self, "mlp", None), "gate_proj", None) else 1)
+                from . import ops
                 dev = group[0].weight.device
-                slab = torch.empty((sum(m.out_features for m in group), group[0].in_features), dtype=dtype, device=dev)
+                rows_all, cols = sum(m.out_features for m in group), group[0].in_features
+                slab = torch.empty((rows_all, cols), dtype=dtype, device=dev)
                 # the LET by-product w @ shift of gate / up IS their bias (no vector kernel in between): stacked as well
-                ws = torch.empty((slab.shape[0],), dtype=torch.float32, device=dev) if group[0] is not nm["q"] else None
+                ws = torch.empty((rows_all,), dtype=torch.float32, device=dev) if group[0] is not nm["q"] else None
+                # integer side channel (ops.IntCodes) of the siblings, stacked the same way: codes + scale | zp | csum vectors
+                codes = vec = None
+                if all(m.int_fprop_eligible(dtype) for m in group):
+                    codes = torch.empty((rows_all, cols), dtype=torch.int8, device=dev)
+                    vec = torch.empty((3, rows_all), dtype=torch.float32, device=dev)
                 r = 0
                 for m in group:
-                    dest[m] = slab[r:r + m.out_features] if ws is None else (slab[r:r + m.out_features], ws[r:r + m.out_features])
-                    r += m.out_features
+                    n = m.out_features
+                    d = ops.WeightDest(slab[r:r + n], None if ws is None else ws[r:r + n])
+                    if codes is not None:
+                        d.codes, d.scale, d.zp, d.csum = codes[r:r + n], vec[0, r:r + n].view(n, 1), vec[1, r:r + n].view(n, 1), vec[2, r:r + n]
+                    dest[m] = d
+                    r += n
         return dest
 
     def _let_temporaries(self, out_dtype, lazy_mlp=False, stack=False):
@@ -142,10 +153,12 @@ class QuantBlockMixin:
         dest = self._weight_slabs(nm, out_dtype) if stack else {}
 
         def quant(mod, sp):
+            want_int = stack and mod.int_fprop_eligible(out_dtype)      # + integer codes for the int8 fprop (ops.IntCodes)
             if sp.shift is not None:
                 return mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype, col_mul=sp.col_mul,
-                                                     row_div=sp.row_div, row_mul=sp.row_mul, shift=sp.shift, out=dest.get(mod))
-            return mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype, out=dest.get(mod)), None
+                                                     row_div=sp.row_div, row_mul=sp.row_mul, shift=sp.shift, out=dest.get(mod),
+                                                     want_int=want_int)
+            return mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype, out=dest.get(mod), want_int=want_int), None
 
         def mlp_bias(mod, wsh):
             if mod is nm["last"]:
@@ -237,15 +250,15 @@ class QuantBlockMixin:
                 for mod in mods:
                     if mod in mlp:
                         def make(mod=mod):
-                            mod.temp_weight, mod.temp_bias = mod.weight_quantizer.quantize(mod.weight, out_dtype=dt,
-                                                                                           out=dest.get(mod)), mod.bias
+                            mod.temp_weight, mod.temp_bias = mod.weight_quantizer.quantize(
+                                mod.weight, out_dtype=dt, out=dest.get(mod), want_int=mod.int_fprop_eligible(dt)), mod.bias
                         mod.temp_weight, mod.temp_bias = None, None
                         mod.use_temporary_parameter = True
                         mod._temp_ready = None
                         mod.__dict__["_lazy_temp"] = make
                     else:
-                        self._publish(mod, mod.weight_quantizer.quantize(mod.weight, out_dtype=dt, out=dest.get(mod)), mod.bias,
-                                      side, forked)
+                        self._publish(mod, mod.weight_quantizer.quantize(mod.weight, out_dtype=dt, out=dest.get(mod),
+                                                                         want_int=mod.int_fprop_eligible(dt)), mod.bias, side, forked)
 
     def clear_temp_variable(self):
         nm = self._let_names()

@@ -5,8 +5,8 @@
 // both operands come from UniformAffineQuantizer grids (quantize/quantizer.py:84-105): with integer codes q_a, q_w, rounded
 // zero-points z_a[t], z_w[n] and scales s_a[t], s_w[n]
 //     Y[t][n] = s_a[t] * s_w[n] * sum_k (q_a[t][k] - z_a[t]) * (q_w[n][k] - z_w[n])  + bias[n] (+ addend)
-// and the sum is an INTEGER.  The quantiser kernels store the codes as int8 (code - off, off = 2^(bits-1), so that 8-bit
-// grids fit) next to their bf16 output; this kernel contracts them on v_mfma_i32_16x16x64_i8 (2x the bf16 rate, half the
+// and the sum is an INTEGER.  The quantiser kernels store the codes as int8 (code - off; off = 0, or 128 for 8-bit grids so
+// that they fit) next to their bf16 output; this kernel contracts them on v_mfma_i32_16x16x64_i8 (2x the bf16 rate, half the
 // operand bytes per MAC) into int32 accumulators -- exact -- and the epilogue applies, in fp32,
 //     sum = acc - za'[t] * Cw[n] - zw'[n] * (Ca[t] - K * za'[t])      za' = z_a - off_a, zw' = z_w - off_w,
 //                                                                      Ca[t] = sum_k stored a-codes, Cw[n] likewise
@@ -294,8 +294,8 @@ extern "C" int oq_gemm_i8(const void* a_codes, const void* b_codes, void* c, con
     p.a = (const int8_t*)a_codes; p.b = (const int8_t*)b_codes; p.c = c; p.bias = bias; p.addend = addend;
     p.sa = a_scale; p.za = a_zp; p.ca = a_csum; p.sw = b_scale; p.zw = b_zp; p.cw = b_csum;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
-    p.off_a = (float)(1 << (a_bits - 1));
-    p.off_w = (float)(1 << (b_bits - 1));
+    p.off_a = a_bits == 8 ? 128.f : 0.f;       // the quantisers store plain grid codes, 8-bit grids as code - 128
+    p.off_w = b_bits == 8 ? 128.f : 0.f;
     hipStream_t st = (hipStream_t)stream;
     const bool fast = K % IBK == 0 && lda % 16 == 0 && ldb % 16 == 0 && oq_aligned16(a_codes) && oq_aligned16(b_codes) &&
                       M >= 8 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && oq_aligned16(c) && (!addend || oq_aligned16(addend)) &&

@@ -219,6 +219,8 @@ struct NQ {
     const void* gx_add;
     float* ws;
     int want_b;
+    int8_t* codes;       // integer side channel of the forward (see FQ::codes / csum in oq_quant_dev.h); optional
+    float* csum;
 };
 
 template <typename TIN, typename TOUT, int CH, bool LN>
@@ -252,6 +254,11 @@ __global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
     const float invK = 1.f / (float)K;
     int par = 0;
+    // integer side channel: the row's code sum rides in a free slot of the NEXT row's first exchange (several waves per row)
+    const bool want_codes = p.codes != nullptr;
+    const bool eight = p.nbits == 8;
+    int64_t pend_r = -1;
+    float pend_v = 0.f;
     for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
         int64_t r = r0 + rslot;
         if (r >= p.rows) r = p.rows - 1;
@@ -267,8 +274,11 @@ __global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
                 s += valid[j] ? sc : 0.f;       // surplus lanes hold a copy of the row's last chunk
             }
         const int op0[4] = {0, 0, 0, 0};
-        float e4[4] = {wave_sum(s), 0.f, 0.f, 0.f};
-        if (nw > 1) row_exchange(red, par, wid, rslot, nw, lane, e4, op0);
+        float e4[4] = {wave_sum(s), pend_v, 0.f, 0.f};
+        if (nw > 1) {
+            row_exchange(red, par, wid, rslot, nw, lane, e4, op0);
+            if (want_codes && pend_r >= 0 && wsub == 0) p.csum[pend_r] = e4[1];      // the previous row's code sum
+        }
         float mean = 0.f, var;
         if (LN) {
             mean = e4[0] * invK;
@@ -319,16 +329,25 @@ __global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
         float inv_s = 0.f;
         const QP q = make_qp(hi, lo, false, 0.f, 0.f, p.nbits, 0, p.inv_q, &inv_s);
         const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad == 0.f;
+        float csl = 0.f;
 #pragma unroll
         for (int j = 0; j < CH; ++j)
             if (j < chn) {
                 float yv[8];
                 if (regular) {
+                    float qv[8];
+                    float cs8 = eight ? -1024.f : 0.f;
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         float tq;
                         const float rq = rne_div(v[j][i], q.s, inv_s, &tq);
-                        yv[i] = (__builtin_amdgcn_fmed3f(rq + q.z, 0.f, Q) - q.z) * q.s;
+                        qv[i] = __builtin_amdgcn_fmed3f(rq + q.z, 0.f, Q);
+                        yv[i] = (qv[i] - q.z) * q.s;
+                        cs8 += qv[i];
+                    }
+                    if (want_codes) {
+                        oq_store_codes8(p.codes + r * K + cc[j], qv, eight);
+                        csl += valid[j] ? cs8 : 0.f;
                     }
                 } else {
 #pragma unroll
@@ -336,6 +355,10 @@ __global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
                         float t = rne_ste(v[j][i] / q.s) + q.z;
                         t = (t != t) ? t : fminf(fmaxf(t, 0.f), Q);
                         yv[i] = (t - q.z) * q.s;
+                    }
+                    if (want_codes) {
+                        const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        oq_store_codes8(p.codes + r * K + cc[j], zero8, false);
                     }
                 }
                 Vec8<TOUT>::store(ybase + r * K + cc[j], yv);
@@ -348,6 +371,18 @@ __global__ void __launch_bounds__(512) normq_fwd_kernel(NQ p, int nw, int chn) {
             p.xmin[r] = lo;
             p.xmax[r] = hi;
         }
+        if (want_codes) {
+            // a row whose scale is 0 / NaN is all-NaN in the reference (quirk Q1): a NaN code sum makes the integer GEMM say so
+            const float cs = regular ? wave_sum(csl) : NAN;
+            if (nw > 1) { pend_r = r; pend_v = cs; }
+            else p.csum[r] = cs;
+        }
+    }
+    if (want_codes && nw > 1) {       // flush the last row's code sum
+        const int op0[4] = {0, 0, 0, 0};
+        float e4[4] = {0.f, pend_v, 0.f, 0.f};
+        row_exchange(red, par, wid, rslot, nw, lane, e4, op0);
+        if (pend_r >= 0 && wsub == 0) p.csum[pend_r] = e4[1];
     }
 }
 
@@ -662,9 +697,13 @@ extern "C" int64_t oq_norm_quant_bwd_workspace(int64_t rows, int64_t cols) {
 }
 
 extern "C" int oq_norm_quant_fwd(const void* x, int dtype, int64_t rows, int64_t cols, const float* w, const float* b, float eps,
-                                 int is_layernorm, int nbits, void* y, float* rstd, float* mean, float* scale, float* zp,
-                                 float* xmin, float* xmax, void* stream) {
+                                 int is_layernorm, int nbits, void* y, int y_dtype, float* rstd, float* mean, float* scale,
+                                 float* zp, float* xmin, float* xmax, void* codes, float* csum, void* stream) {
     OQ_CHECK_ARG(x && y && w && rstd && scale && zp && xmin && xmax, "oq_norm_quant_fwd: null pointer");
+    OQ_CHECK_ARG((codes == nullptr) == (csum == nullptr) && (!codes || nbits <= 8),
+                 "oq_norm_quant_fwd: codes and csum go together and need a grid of at most 8 bits");
+    OQ_CHECK_ARG(y_dtype == dtype || (dtype == OQ_F32 && y_dtype == OQ_BF16),
+                 "oq_norm_quant_fwd: output dtype %d for input dtype %d (same, or bf16 from f32)", y_dtype, dtype);
     OQ_CHECK_ARG(oq_aligned16(x) && oq_aligned16(y) && oq_aligned16(w) && oq_aligned16(b), "oq_norm_quant_fwd: 16-byte alignment");
     OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_norm_quant_fwd: rows %lld, bitwidth %d", (long long)rows, nbits);
     OQ_CHECK_ARG(!is_layernorm || mean, "oq_norm_quant_fwd: layernorm needs the mean buffer");
@@ -677,20 +716,22 @@ extern "C" int oq_norm_quant_fwd(const void* x, int dtype, int64_t rows, int64_t
     p.x = x; p.y = y; p.w = w; p.b = b; p.rows = rows; p.cols = cols; p.eps = eps; p.ln = is_layernorm; p.nbits = nbits;
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.rstd = rstd; p.mean = mean; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax;
+    p.codes = (int8_t*)codes; p.csum = csum;
     const int rpb = g.wpb / g.nw;
     const int64_t need = (rows + rpb - 1) / rpb, cap = (int64_t)n_cus() * 8;
     const dim3 grid((unsigned)(need < cap ? need : cap)), blk((unsigned)(g.wpb * 64));
     const size_t smem = sizeof(float) * (2 * cols + 64);
     hipStream_t st = (hipStream_t)stream;
-#define NQ_FWD(T_, LN_) do { if (g.chn <= 4) hipLaunchKernelGGL((normq_fwd_kernel<T_, T_, 4, LN_>), grid, blk, smem, st, p, g.nw, g.chn); \
-                             else hipLaunchKernelGGL((normq_fwd_kernel<T_, T_, 8, LN_>), grid, blk, smem, st, p, g.nw, g.chn); } while (0)
-    if (dtype == OQ_BF16) { if (is_layernorm) NQ_FWD(bf16_t, true); else NQ_FWD(bf16_t, false); }
-    else { if (is_layernorm) NQ_FWD(float, true); else NQ_FWD(float, false); }
+#define NQ_FWD(T_, TY_, LN_) do { if (g.chn <= 4) hipLaunchKernelGGL((normq_fwd_kernel<T_, TY_, 4, LN_>), grid, blk, smem, st, p, g.nw, g.chn); \
+                             else hipLaunchKernelGGL((normq_fwd_kernel<T_, TY_, 8, LN_>), grid, blk, smem, st, p, g.nw, g.chn); } while (0)
+    if (dtype == OQ_BF16) { if (is_layernorm) NQ_FWD(bf16_t, bf16_t, true); else NQ_FWD(bf16_t, bf16_t, false); }
+    else if (y_dtype == OQ_BF16) { if (is_layernorm) NQ_FWD(float, bf16_t, true); else NQ_FWD(float, bf16_t, false); }
+    else { if (is_layernorm) NQ_FWD(float, float, true); else NQ_FWD(float, float, false); }
     OQ_CHECK_LAUNCH("oq_norm_quant_fwd");
     return OQ_OK;
 }
 
-extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, const void* g2, const void* g3, int dtype, int64_t rows, int64_t cols, const float* w,
+extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, const void* g2, const void* g3, int dtype, int g_dtype, int64_t rows, int64_t cols, const float* w,
                                  const float* b, const float* rstd, const float* mean, int is_layernorm, int nbits,
                                  const float* xmin, const float* xmax, void* gx, float* gw, float* gb, const void* gx_addend,
                                  float* workspace, int64_t workspace_floats, void* stream) {
@@ -698,6 +739,8 @@ extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, const void* g2, 
     OQ_CHECK_ARG(oq_aligned16(x) && oq_aligned16(g_) && oq_aligned16(gx) && oq_aligned16(w) && oq_aligned16(b) && oq_aligned16(gx_addend),
                  "oq_norm_quant_bwd: 16-byte alignment");
     OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_norm_quant_bwd: rows %lld, bitwidth %d", (long long)rows, nbits);
+    OQ_CHECK_ARG(g_dtype == dtype || (dtype == OQ_F32 && g_dtype == OQ_BF16),
+                 "oq_norm_quant_bwd: gradient dtype %d for input dtype %d (same, or bf16 with an f32 input)", g_dtype, dtype);
     RowGeo g;
     if (!oq_norm_quant_supported(dtype, cols) || !normq_bwd_geo(cols, &g)) {
         oq_set_error("oq_norm_quant_bwd: dtype %d / %lld columns unsupported", dtype, (long long)cols);
@@ -715,11 +758,11 @@ extern "C" int oq_norm_quant_bwd(const void* x, const void* g_, const void* g2, 
     const dim3 grid((unsigned)nblk), blk((unsigned)(g.wpb * 64));
     const size_t smem = sizeof(float) * (2 * cols + 64 + (size_t)g.wpb * g.chn * 512);
     hipStream_t st = (hipStream_t)stream;
-#define NQ_BWD_K(T_, C_, LN_) ((const void*)normq_bwd_kernel<T_, T_, C_, LN_>)
-#define NQ_BWD_SEL(T_) (g.chn <= 2 ? (is_layernorm ? NQ_BWD_K(T_, 2, true) : NQ_BWD_K(T_, 2, false))  \
-                      : g.chn <= 4 ? (is_layernorm ? NQ_BWD_K(T_, 4, true) : NQ_BWD_K(T_, 4, false))  \
-                                   : (is_layernorm ? NQ_BWD_K(T_, 8, true) : NQ_BWD_K(T_, 8, false)))
-    const void* k = dtype == OQ_BF16 ? NQ_BWD_SEL(bf16_t) : NQ_BWD_SEL(float);
+#define NQ_BWD_K(T_, TG_, C_, LN_) ((const void*)normq_bwd_kernel<T_, TG_, C_, LN_>)
+#define NQ_BWD_SEL(T_, TG_) (g.chn <= 2 ? (is_layernorm ? NQ_BWD_K(T_, TG_, 2, true) : NQ_BWD_K(T_, TG_, 2, false))  \
+                      : g.chn <= 4 ? (is_layernorm ? NQ_BWD_K(T_, TG_, 4, true) : NQ_BWD_K(T_, TG_, 4, false))  \
+                                   : (is_layernorm ? NQ_BWD_K(T_, TG_, 8, true) : NQ_BWD_K(T_, TG_, 8, false)))
+    const void* k = dtype == OQ_BF16 ? NQ_BWD_SEL(bf16_t, bf16_t) : (g_dtype == OQ_BF16 ? NQ_BWD_SEL(float, bf16_t) : NQ_BWD_SEL(float, float));
     if (smem > 64 * 1024 && hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
         oq_set_error("oq_norm_quant_bwd: cannot reserve %zu bytes of LDS", smem);
         return OQ_E_LAUNCH;

@@ -792,7 +792,14 @@ bool needs_generic(int64_t cols, int64_t seg) {
 extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_t cols, int64_t seg, int nbits,
                                 int symmetric, const float* col_mul, const float* row_div, const float* row_mul,
                                 const float* shift, const float* up, const float* low, void* y, int y_dtype,
-                                float* scale, float* zp, float* xmin, float* xmax, float* wshift, void* stream) {
+                                float* scale, float* zp, float* xmin, float* xmax, float* wshift, void* codes, float* csum,
+                                void* stream) {
+    OQ_CHECK_ARG((codes == nullptr) == (csum == nullptr), "oq_fakequant_fwd: codes and csum must both be given or both NULL");
+    if (codes && !oq_fakequant_codes_supported(cols, seg, nbits, (col_mul || row_div || row_mul || shift) ? 1 : 0)) {
+        oq_set_error("oq_fakequant_fwd: integer codes are not available for cols %lld seg %lld nbits %d "
+                     "(oq_fakequant_codes_supported)", (long long)cols, (long long)seg, nbits);
+        return OQ_E_UNSUPPORTED;
+    }
     if (needs_generic(cols, seg)) {
         OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits <= 16, "oq_fakequant_fwd: bad shape / bitwidth %d", nbits);
         OQ_CHECK_ARG(w && y && scale && zp && xmin && xmax, "oq_fakequant_fwd: null pointer");
@@ -836,9 +843,14 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.col_mul = col_mul; p.row_div = row_div; p.row_mul = row_mul; p.shift = wshift ? shift : nullptr;
     p.up = up; p.low = low; p.y = y; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax; p.wshift = wshift;
+    p.codes = (int8_t*)codes; p.csum = csum;
     {   // whole-row segments: the wave-per-row kernels (oq_rowq.hip) take them when the shape is theirs
         const int rq = oq_rowq_fwd(p, w_dtype, y_dtype, stream);
         if (rq <= 0) return rq;
+    }
+    if (codes) {
+        oq_set_error("oq_fakequant_fwd: integer codes requested but the wave-per-row kernels did not take the problem");
+        return OQ_E_UNSUPPORTED;
     }
     const bool let = col_mul || row_div || row_mul || shift;
     int ch, bt;
@@ -997,7 +1009,9 @@ extern "C" int oq_fakequant_fwd_multi(const oq_fakequant_fwd_args* a, int n, voi
             ok = !needs_generic(t.cols, t.seg) && check_shape("oq_fakequant_fwd_multi", t.rows, t.cols, t.seg, t.nbits) == OQ_OK &&
                  t.w && t.y && t.scale && t.zp && t.xmin && t.xmax && oq_aligned16(t.w) && oq_aligned16(t.y) &&
                  oq_aligned16(t.col_mul) && oq_aligned16(t.shift) && ((t.up == nullptr) == (t.low == nullptr)) &&
-                 (!t.wshift || t.shift) && t.w_dtype == a[0].w_dtype && t.y_dtype == a[0].y_dtype;
+                 (!t.wshift || t.shift) && t.w_dtype == a[0].w_dtype && t.y_dtype == a[0].y_dtype &&
+                 ((t.codes == nullptr) == (t.csum == nullptr)) &&
+                 (!t.codes || oq_fakequant_codes_supported(t.cols, t.seg, t.nbits, (t.col_mul || t.row_div || t.row_mul || t.shift) ? 1 : 0));
             if (!ok) break;
             FQ p{};
             p.w = t.w; p.rows = t.rows; p.cols = t.cols; p.seg = t.seg; p.nbits = t.nbits; p.symmetric = t.symmetric;
@@ -1005,6 +1019,7 @@ extern "C" int oq_fakequant_fwd_multi(const oq_fakequant_fwd_args* a, int n, voi
             p.col_mul = t.col_mul; p.row_div = t.row_div; p.row_mul = t.row_mul; p.shift = t.wshift ? t.shift : nullptr;
             p.up = t.up; p.low = t.low; p.y = t.y; p.scale = t.scale; p.zp = t.zp; p.xmin = t.xmin; p.xmax = t.xmax;
             p.wshift = t.wshift;
+            p.codes = (int8_t*)t.codes; p.csum = t.csum;
             ps[i] = p;
         }
         if (ok) {
@@ -1015,7 +1030,8 @@ extern "C" int oq_fakequant_fwd_multi(const oq_fakequant_fwd_args* a, int n, voi
     for (int i = 0; i < n; ++i) {
         const oq_fakequant_fwd_args& t = a[i];
         const int rc = oq_fakequant_fwd(t.w, t.w_dtype, t.rows, t.cols, t.seg, t.nbits, t.symmetric, t.col_mul, t.row_div, t.row_mul,
-                                        t.shift, t.up, t.low, t.y, t.y_dtype, t.scale, t.zp, t.xmin, t.xmax, t.wshift, stream);
+                                        t.shift, t.up, t.low, t.y, t.y_dtype, t.scale, t.zp, t.xmin, t.xmax, t.wshift, t.codes, t.csum,
+                                        stream);
         if (rc) return rc;
     }
     return OQ_OK;

@@ -28,7 +28,28 @@ struct FQ {
     const void* w2;
     void* gx2;
     int64_t ldw;          // row stride (elements) of w / w2 and gx / gx2 in the fused-producer kernels; 0 = cols
+    // integer side channel of the forward (whole-row segments, nbits <= 8; optional): the grid codes as int8 -- plain codes
+    // 0 .. 2^nbits-1, for 8-bit grids code - 128 -- and per row the sum of the STORED codes (NaN for a row whose scale is 0 / NaN,
+    // so that the integer GEMM's output is NaN where the reference's is).  Consumed by oq_gemm_i8.
+    int8_t* codes;
+    float* csum;
 };
+
+// 8 grid codes (floats holding integers 0 .. 255) -> 8 bytes; v_cvt_pk_u8_f32 converts and places one byte per instruction
+__device__ __forceinline__ void oq_store_codes8(int8_t* dst, const float (&c)[8], bool eight_bit) {
+    uint32_t lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(c[0], 0, lo);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(c[1], 1, lo);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(c[2], 2, lo);
+    lo = __builtin_amdgcn_cvt_pk_u8_f32(c[3], 3, lo);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(c[4], 0, hi);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(c[5], 1, hi);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(c[6], 2, hi);
+    hi = __builtin_amdgcn_cvt_pk_u8_f32(c[7], 3, hi);
+    if (eight_bit) { lo ^= 0x80808080u; hi ^= 0x80808080u; }     // code - 128 as a signed byte
+    typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+    *reinterpret_cast<u32x2*>(dst) = u32x2{lo, hi};
+}
 
 namespace {
 

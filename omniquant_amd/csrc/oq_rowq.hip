@@ -83,6 +83,12 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
     TOUT* ybase = reinterpret_cast<TOUT*>(p.y);
     const bool lwc = p.up != nullptr;
     int par = 0;
+    // integer side channel (FQ::codes / csum): the row's code sum needs one more row-wide reduction; with several waves per row
+    // it rides in the free slot of the NEXT row's min / max exchange (no extra barrier per row), flushed once after the loop
+    const bool want_codes = !LET && p.codes != nullptr;
+    const bool eight = p.nbits == 8;
+    int64_t pend_r = -1;
+    float pend_v = 0.f;
     for (int64_t r0 = (int64_t)blockIdx.x * rpb; r0 < p.rows; r0 += (int64_t)gridDim.x * rpb) {
         int64_t r = r0 + rslot;
         if (r >= p.rows) r = p.rows - 1;              // surplus waves redo the last row: same values stored again
@@ -134,10 +140,11 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
                 }
             }
         }
-        float v4[4] = {wave_max(hi), wave_min(lo), nanm != 0 ? 1.f : 0.f, LET ? wave_sum(dot) : 0.f};
+        float v4[4] = {wave_max(hi), wave_min(lo), nanm != 0 ? 1.f : 0.f, LET ? wave_sum(dot) : pend_v};
         if (nw > 1) {
             const int op[4] = {1, 2, 1, 0};
             row_exchange(red, par, wid, rslot, nw, lane, v4, op);
+            if (want_codes && pend_r >= 0 && wsub == 0) p.csum[pend_r] = v4[3];     // the previous row's code sum
         }
         hi = v4[0]; lo = v4[1];
         const float bad = v4[2];
@@ -147,6 +154,7 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
         const QP q = make_qp(hi, lo, lwc, upl, lowl, p.nbits, p.symmetric, p.inv_q, &inv_s);
         const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad == 0.f;     // wave-uniform
         TOUT* yrow = ybase + r * K;
+        float csl = 0.f;                              // this lane's share of the row's code sum
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
             if (j < chn) {
@@ -154,6 +162,31 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
                 if (p.nbits >= 16) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) yv[i] = x[j][i];
+                } else if (regular && want_codes) {
+                    float rq[8], qv[8];
+                    uint64_t susp = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float tq = x[j][i] * inv_s;
+                        rq[i] = rintf(tq);
+                        susp |= __builtin_amdgcn_fcmpf(fabsf(tq - rq[i]), fmaf(-4e-7f, fabsf(tq), 0.5f), 2);   // FCMP_OGT
+                    }
+                    if (susp != 0) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float tq = x[j][i] * inv_s;
+                            if (fabsf(tq - rq[i]) > fmaf(-4e-7f, fabsf(tq), 0.5f)) rq[i] = rintf(x[j][i] / q.s);
+                        }
+                    }
+                    float cs8 = eight ? -1024.f : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        qv[i] = __builtin_amdgcn_fmed3f(rq[i] + q.z, 0.f, Q);
+                        yv[i] = (qv[i] - q.z) * q.s;
+                        cs8 += qv[i];
+                    }
+                    oq_store_codes8(p.codes + r * K + cc[j], qv, eight);
+                    csl += valid[j] ? cs8 : 0.f;      // surplus lanes redo the row's last chunk
                 } else if (regular) {
                     float rq[8];
                     uint64_t susp = 0;
@@ -181,6 +214,10 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
                     }
                 }
                 Vec8<TOUT>::store(yrow + cc[j], yv);
+                if (want_codes && !(regular && p.nbits < 16)) {
+                    const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    oq_store_codes8(p.codes + r * K + cc[j], zero8, false);
+                }
             }
         }
         if (wsub == 0) {      // every lane stores the same value (no divergent branch around the stores)
@@ -190,6 +227,18 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
             p.xmax[r] = hi;
             if (LET && p.wshift) p.wshift[r] = dot;
         }
+        if (want_codes) {
+            // a row whose scale is 0 / NaN is all-NaN in the reference (quirk Q1): a NaN code sum makes the integer GEMM say so
+            const float cs = (regular && p.nbits < 16) ? wave_sum(csl) : NAN;
+            if (nw > 1) { pend_r = r; pend_v = cs; }
+            else p.csum[r] = cs;
+        }
+    }
+    if (want_codes && nw > 1) {       // flush the last row's code sum (every wave of the workgroup walked the same number of rows)
+        float v4[4] = {0.f, 0.f, 0.f, pend_v};
+        const int op[4] = {1, 2, 1, 0};
+        row_exchange(red, par, wid, rslot, nw, lane, v4, op);
+        if (pend_r >= 0 && wsub == 0) p.csum[pend_r] = v4[3];
     }
 }
 
@@ -496,6 +545,7 @@ template <int RGT>
 struct LetqFwdSmem {        // declared once per KERNEL (a body instantiated per row mode would otherwise get one copy each)
     float part[4][RGT][4];
     float qps[RGT][4];
+    float csp[4][RGT];      // per-wave code sums of the group's rows (integer side channel)
 };
 
 template <typename TIN, typename TOUT, int CH, int MODE, int RGT>
@@ -503,11 +553,17 @@ __device__ __forceinline__ void letq_fwd_body(const FQ& p, const int bid, const 
     constexpr bool has_rd = (MODE & 1) != 0, has_rm = (MODE & 2) != 0;
     float (&part)[4][RGT][4] = sm.part;
     float (&qps)[RGT][4] = sm.qps;
+    float (&csp)[4][RGT] = sm.csp;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int K = (int)p.cols;
     const int nchunks = K >> 3;
     const float Q = (float)((1 << p.nbits) - 1);
+    // integer side channel (FQ::codes / csum): phase C leaves per-wave code sums in `csp`; wave w adds them up for row w of the
+    // group in phase B of the workgroup's NEXT group (behind that group's first barrier: no extra barrier), once more after the loop
+    const bool want_codes = p.codes != nullptr && p.nbits <= 8;
+    const bool eight = p.nbits == 8;
+    int64_t pend_r0 = -1;
     bool valid[CH];
     int cc[CH];
     float cm[CH][8], sh[CH][8];
@@ -571,6 +627,10 @@ __device__ __forceinline__ void letq_fwd_body(const FQ& p, const int bid, const 
         // ---- phase B: wave w finalises row w ------------------------------------------------------------------------
         if (wid < RGT) {
             const int rr = wid;
+            if (want_codes && pend_r0 >= 0) {          // code sum of row w of the previous group
+                const int64_t rp = pend_r0 + rr < p.rows ? pend_r0 + rr : p.rows - 1;
+                p.csum[rp] = (csp[0][rr] + csp[1][rr]) + (csp[2][rr] + csp[3][rr]);
+            }
             float hi = -INFINITY, lo = INFINITY, bad = 0.f, dot = 0.f;
 #pragma unroll
             for (int w2 = 0; w2 < 4; ++w2) {
@@ -597,6 +657,7 @@ __device__ __forceinline__ void letq_fwd_body(const FQ& p, const int bid, const 
             const float qs = q4[0], qz = q4[1], inv_s = q4[2];
             const bool regular = q4[3] != 0.f;
             TOUT* yrow = ybase + rows_[rr] * K;
+            float csl = 0.f;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 float yv[8];
@@ -619,8 +680,21 @@ __device__ __forceinline__ void letq_fwd_body(const FQ& p, const int bid, const 
                             if (fabsf(tq - rq[i]) > fmaf(-4e-7f, fabsf(tq), 0.5f)) rq[i] = rintf(x[rr][j][i] / qs);
                         }
                     }
+                    if (want_codes) {
+                        float qv[8];
+                        float cs8 = eight ? -1024.f : 0.f;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) yv[i] = (__builtin_amdgcn_fmed3f(rq[i] + qz, 0.f, Q) - qz) * qs;
+                        for (int i = 0; i < 8; ++i) {
+                            qv[i] = __builtin_amdgcn_fmed3f(rq[i] + qz, 0.f, Q);
+                            yv[i] = (qv[i] - qz) * qs;
+                            cs8 += qv[i];
+                        }
+                        oq_store_codes8(p.codes + rows_[rr] * K + cc[j], qv, eight);
+                        csl += valid[j] ? cs8 : 0.f;          // surplus lanes redo the row's last chunk
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) yv[i] = (__builtin_amdgcn_fmed3f(rq[i] + qz, 0.f, Q) - qz) * qs;
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -628,9 +702,26 @@ __device__ __forceinline__ void letq_fwd_body(const FQ& p, const int bid, const 
                         v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
                         yv[i] = (v - qz) * qs;
                     }
+                    if (want_codes) {
+                        const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        oq_store_codes8(p.codes + rows_[rr] * K + cc[j], zero8, false);
+                    }
                 }
                 Vec8<TOUT>::store(yrow + cc[j], yv);
             }
+            if (want_codes) {
+                // a row whose scale is 0 / NaN is all-NaN in the reference (quirk Q1): a NaN code sum makes the integer GEMM say so
+                const float cs = regular ? wave_sum(csl) : NAN;
+                if (lane == 0) csp[wid][rr] = cs;
+            }
+        }
+        pend_r0 = r0;
+    }
+    if (want_codes) {
+        __syncthreads();
+        if (wid < RGT && pend_r0 >= 0) {
+            const int64_t rp = pend_r0 + wid < p.rows ? pend_r0 + wid : p.rows - 1;
+            p.csum[rp] = (csp[0][wid] + csp[1][wid]) + (csp[2][wid] + csp[3][wid]);
         }
     }
 }
@@ -1148,6 +1239,15 @@ int oq_letq_bwd_multi(FQ* ps, int n, int w_dtype, int g_dtype, const int64_t* wo
     return OQ_OK;
 }
 
+// The kernels that write the integer side channel (FQ::codes / csum): whole-row segments on grids of at most 8 bits; LET
+// weights on the row-group kernels, everything else on the wave-per-row kernel without LET.
+extern "C" int64_t oq_fakequant_codes_supported(int64_t cols, int64_t seg, int nbits, int let) {
+    if (seg != cols || nbits < 2 || nbits > 8 || env_i("OQ_ROWQ", 1) == 0) return 0;
+    if (let) return letq_ch(cols) != 0 ? 1 : 0;
+    RowGeo g;
+    return row_geo(cols, (int)env_i("OQ_ROWQ_FWD_NW", 0), &g) ? 1 : 0;
+}
+
 int oq_rowq_fwd(const FQ& p, int w_dtype, int y_dtype, void* stream) {
     if (p.seg != p.cols || env_i("OQ_ROWQ", 1) == 0) return 1;
     const bool let = p.col_mul || p.row_div || p.row_mul || p.shift;
@@ -1287,7 +1387,8 @@ int oq_rowq_bwd(const FQ& pin, int w_dtype, int g_dtype, float* workspace, int64
 }
 
 // ---- fused silu(gate) * up -> per-token fake quant (the down_proj input of QuantLlamaMLP) -----------------------------
-template <typename T>
+// TP: dtype of gate / up (the projection's output); TY: dtype of y (forward) resp. of the gradients g, ggate, gup (backward)
+template <typename TP, typename TY>
 static int silu_q_launch(bool fwd, FQ& p, void* stream) {
     RowGeo g;
     // two inputs (and two gradient outputs) per element: 8 waves per row for the long rows of the MLP (3-4 chunks per lane,
@@ -1306,19 +1407,22 @@ static int silu_q_launch(bool fwd, FQ& p, void* stream) {
     const size_t smem = sizeof(float) * 64;
     hipStream_t st = (hipStream_t)stream;
     if (fwd) {
-        if (g.chn <= 4) hipLaunchKernelGGL((rowq_fwd_kernel<T, T, false, 4, 1>), grid, blk, smem, st, p, g.nw, g.chn);
-        else hipLaunchKernelGGL((rowq_fwd_kernel<T, T, false, 8, 1>), grid, blk, smem, st, p, g.nw, g.chn);
+        if (g.chn <= 4) hipLaunchKernelGGL((rowq_fwd_kernel<TP, TY, false, 4, 1>), grid, blk, smem, st, p, g.nw, g.chn);
+        else hipLaunchKernelGGL((rowq_fwd_kernel<TP, TY, false, 8, 1>), grid, blk, smem, st, p, g.nw, g.chn);
     } else {
-        if (g.chn <= 4) hipLaunchKernelGGL((rowq_bwd_kernel<T, T, false, 4, 1>), grid, blk, smem, st, p, g.nw, g.chn);
-        else hipLaunchKernelGGL((rowq_bwd_kernel<T, T, false, 8, 1>), grid, blk, smem, st, p, g.nw, g.chn);
+        if (g.chn <= 4) hipLaunchKernelGGL((rowq_bwd_kernel<TP, TY, false, 4, 1>), grid, blk, smem, st, p, g.nw, g.chn);
+        else hipLaunchKernelGGL((rowq_bwd_kernel<TP, TY, false, 8, 1>), grid, blk, smem, st, p, g.nw, g.chn);
     }
     OQ_CHECK_LAUNCH("oq_silu_mul_quant");
     return OQ_OK;
 }
 
 extern "C" int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype, int64_t rows, int64_t cols, int64_t ld, int nbits,
-                                     void* y, float* scale, float* zp, float* xmin, float* xmax, void* stream) {
+                                     void* y, int y_dtype, float* scale, float* zp, float* xmin, float* xmax, void* codes,
+                                     float* csum, void* stream) {
     OQ_CHECK_ARG(gate && up && y && scale && zp && xmin && xmax, "oq_silu_mul_quant_fwd: null pointer");
+    OQ_CHECK_ARG((codes == nullptr) == (csum == nullptr) && (!codes || nbits <= 8),
+                 "oq_silu_mul_quant_fwd: codes and csum go together and need a grid of at most 8 bits");
     OQ_CHECK_ARG(ld == 0 || (ld >= cols && ld % 8 == 0), "oq_silu_mul_quant_fwd: ld %lld (0 or a multiple of 8 >= cols)", (long long)ld);
     OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_silu_mul_quant_fwd: rows %lld, bitwidth %d", (long long)rows, nbits);
     OQ_CHECK_ARG(oq_aligned16(gate) && oq_aligned16(up) && oq_aligned16(y), "oq_silu_mul_quant_fwd: 16-byte alignment");
@@ -1326,15 +1430,17 @@ extern "C" int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype
     p.w = gate; p.w2 = up; p.rows = rows; p.cols = cols; p.seg = cols; p.nbits = nbits; p.ldw = ld;
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.y = y; p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax;
-    if (dtype == OQ_BF16) return silu_q_launch<bf16_t>(true, p, stream);
-    if (dtype == OQ_F32) return silu_q_launch<float>(true, p, stream);
-    oq_set_error("oq_silu_mul_quant_fwd: dtype %d unsupported", dtype);
+    p.codes = (int8_t*)codes; p.csum = csum;
+    if (dtype == OQ_BF16 && y_dtype == OQ_BF16) return silu_q_launch<bf16_t, bf16_t>(true, p, stream);
+    if (dtype == OQ_F32 && y_dtype == OQ_F32) return silu_q_launch<float, float>(true, p, stream);
+    if (dtype == OQ_F32 && y_dtype == OQ_BF16) return silu_q_launch<float, bf16_t>(true, p, stream);   // fp32 pre-activations
+    oq_set_error("oq_silu_mul_quant_fwd: dtypes in %d / out %d unsupported", dtype, y_dtype);
     return OQ_E_UNSUPPORTED;
 }
 
-extern "C" int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int64_t rows, int64_t cols,
-                                     int64_t ld, int nbits, const float* xmin, const float* xmax, void* ggate, void* gup,
-                                     void* stream) {
+extern "C" int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int g_dtype, int64_t rows,
+                                     int64_t cols, int64_t ld, int nbits, const float* xmin, const float* xmax, void* ggate,
+                                     void* gup, void* stream) {
     OQ_CHECK_ARG(gate && up && g && ggate && gup && xmin && xmax, "oq_silu_mul_quant_bwd: null pointer");
     OQ_CHECK_ARG(ld == 0 || (ld >= cols && ld % 8 == 0), "oq_silu_mul_quant_bwd: ld %lld (0 or a multiple of 8 >= cols)", (long long)ld);
     OQ_CHECK_ARG(rows > 0 && nbits >= 2 && nbits < 16, "oq_silu_mul_quant_bwd: rows %lld, bitwidth %d", (long long)rows, nbits);
@@ -1344,8 +1450,9 @@ extern "C" int oq_silu_mul_quant_bwd(const void* gate, const void* up, const voi
     p.w = gate; p.w2 = up; p.g = g; p.rows = rows; p.cols = cols; p.seg = cols; p.nbits = nbits; p.ldw = ld;
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.xmin = const_cast<float*>(xmin); p.xmax = const_cast<float*>(xmax); p.gx = ggate; p.gx2 = gup;
-    if (dtype == OQ_BF16) return silu_q_launch<bf16_t>(false, p, stream);
-    if (dtype == OQ_F32) return silu_q_launch<float>(false, p, stream);
-    oq_set_error("oq_silu_mul_quant_bwd: dtype %d unsupported", dtype);
+    if (dtype == OQ_BF16 && g_dtype == OQ_BF16) return silu_q_launch<bf16_t, bf16_t>(false, p, stream);
+    if (dtype == OQ_F32 && g_dtype == OQ_F32) return silu_q_launch<float, float>(false, p, stream);
+    if (dtype == OQ_F32 && g_dtype == OQ_BF16) return silu_q_launch<float, bf16_t>(false, p, stream);
+    oq_set_error("oq_silu_mul_quant_bwd: dtypes %d / gradients %d unsupported", dtype, g_dtype);
     return OQ_E_UNSUPPORTED;
 }

@@ -9,9 +9,13 @@ from .quantizer import UniformAffineQuantizer
 
 
 def _hip_linear(input, weight, bias=None, residual=None, sib=None):
+    xint, wint = getattr(input, "_oq_int", None), getattr(weight, "_oq_int", None)
     if weight.dtype != input.dtype:
         weight = ops.cast(weight, input.dtype)
-    return ops.LinearFn.apply(input, weight, bias, residual, sib)
+    if xint is None or wint is None or not ops.int_fprop_on():
+        xint = wint = None
+    # both operands carry their integer codes (ops.IntCodes): the fprop runs on the int8 MFMA, exactly
+    return ops.LinearFn.apply(input, weight, bias, residual, sib, xint, wint)
 
 
 class QuantLinear(nn.Module):
@@ -56,12 +60,28 @@ class QuantLinear(nn.Module):
     def drop_cache(self):
         self._wcache, self._wcache_key = None, None
 
+    def int_fprop_eligible(self, dtype):
+        """True when this linear's fprop can run on integer codes (ops.gemm_i8) for activations of `dtype`: production mode
+        (bf16), the plain dynamic per-token input quantiser and a per-channel (ungrouped) weight quantiser, both on grids
+        of at most 8 bits, and the HIP GEMM as forward function.  OQ_INT_FPROP=0 switches the path off."""
+        aq, wq = self.act_quantizer, self.weight_quantizer
+        return (ops.int_fprop_on() and dtype == torch.bfloat16 and self.fwd_func is _hip_linear and not self.fwd_kwargs
+                and self.use_act_quant and aq is not None and not self.disable_input_quant and aq.enable and 2 <= aq.n_bits <= 8
+                and not aq.group_size and aq.metric != "fix0to1" and aq.dynamic_method == "per_token"
+                and wq.enable and 2 <= wq.n_bits <= 8 and not wq.group_size and wq.metric != "fix0to1"
+                and self.in_features % 16 == 0
+                and ops.int_codes_supported(self.in_features, self.in_features, wq.n_bits, False))
+
     def quantize_input(self, input):
         """Per-token fake quant of the input, exposed so that sibling projections reading the SAME tensor with
         identical quantizer settings (q/k/v; gate/up) share one quantisation pass (reference quirk Q7: the three
         results are bit-identical)."""
         if self.use_act_quant and not self.disable_input_quant:
-            return self.act_quantizer(input)
+            aq = self.act_quantizer
+            if (input.is_cuda and aq.dynamic_method == "per_token" and aq.metric != "fix0to1" and not aq._identity()
+                    and self.int_fprop_eligible(input.dtype) and self.use_temporary_parameter):
+                return aq.quantize(input, want_int=True)          # + integer codes for the int8 fprop (same values)
+            return aq(input)
         return input
 
     def _resolve(self, dtype):

@@ -45,22 +45,33 @@ class QuantLlamaMLP(nn.Module):
         if all(m.use_temporary_parameter and m.fwd_func is _hip_linear and not m.fwd_kwargs
                and m.__dict__.get("_stat_sink") is None for m in (g_, u_)) and xq.dtype in (torch.bfloat16, torch.float32) \
                 and g_.out_features % 8 == 0:
+            xint = getattr(xq, "_oq_int", None)
             (wg, bg), (wu, bu) = g_._resolve(xq.dtype), u_._resolve(xq.dtype)
             if wg.dtype == xq.dtype and ops.stacked_rows([wg, wu]) is not None and ops.stacked_vectors([bg, bu]) is not False:
                 # the two fake-quant weights are row blocks of one buffer (block_common._weight_slabs): gate | up as ONE GEMM
                 # per direction, silu*up (-> down_proj input quantiser) reading the column blocks in place
                 nb = dq.n_bits if (fuse_q and ops.silu_mul_quant_supported(xq.new_empty((0, g_.out_features)), dq.n_bits)) else 0
-                stash = {}
-                act = ops.StackedGateUpFn.apply(xq, wg, bg, wu, bu, nb, stash, sib)
+                # integer codes of the operands (ops.IntCodes), when all three carry them: exact int8 fprop
+                wints = (getattr(wg, "_oq_int", None), getattr(wu, "_oq_int", None))
+                if xint is None or any(w is None for w in wints) or not ops.int_fprop_on():
+                    xint = wints = None
+                stash = {"want_int": True} if (nb and self.down_proj.use_temporary_parameter
+                                               and self.down_proj.int_fprop_eligible(xq.dtype)) else {}
+                act = ops.StackedGateUpFn.apply(xq, wg, bg, wu, bu, nb, stash, sib, xint, wints)
                 if nb:
                     dq.scale, dq.round_zero_point = stash["scale"], stash["zp"]
+                    if stash.get("int") is not None:
+                        act._oq_int = stash["int"]
                 return self.down_proj(act, input_is_quantized=bool(nb), residual=residual)
         gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq, sib)
         if fuse_q and ops.silu_mul_quant_supported(gate, dq.n_bits):
             # act_fn(gate) * up and the down_proj input quantiser in ONE kernel: the product is never stored
-            stash = {}
+            stash = {"want_int": True} if (self.down_proj.use_temporary_parameter
+                                           and self.down_proj.int_fprop_eligible(gate.dtype)) else {}
             act = ops.SiluMulQuantFn.apply(gate, up, dq.n_bits, stash)
             dq.scale, dq.round_zero_point = stash["scale"], stash["zp"]
+            if stash.get("int") is not None:
+                act._oq_int = stash["int"]
             return self.down_proj(act, input_is_quantized=True, residual=residual)
         return self.down_proj(ops.SiluMulFn.apply(gate, up), residual=residual)   # residual add fused into the GEMM store
 
@@ -179,8 +190,13 @@ class QuantLlamaAttention(nn.Module):
             if same_bits and os.environ.get("OQ_MERGED_QKV", "1") != "0":
                 # one node for the three: RoPE + head quant of all heads in one launch per direction, one bias column sum
                 stashes = [{}, {}, {}]
+                # integer codes of the shared input and of the three weights (ops.IntCodes), when all carry them: exact int8 fprop
+                xint = getattr(hq, "_oq_int", None)
+                wints = tuple(getattr(w, "_oq_int", None) for w, _ in wbs)
+                if xint is None or any(w is None for w in wints) or not ops.int_fprop_on():
+                    xint = wints = None
                 q, k, v = ops.QKVRopeQuantFn.apply(hq, wbs[0][0], wbs[0][1], wbs[1][0], wbs[1][1], wbs[2][0], wbs[2][1], cos, sin,
-                                                   trio[0][1].n_bits, hd, stashes, sib)
+                                                   trio[0][1].n_bits, hd, stashes, sib, xint, wints)
                 for (_, qz, _), st in zip(trio, stashes):
                     qz.scale, qz.round_zero_point = st["scale"], st["zp"]
             else:

@@ -26,9 +26,12 @@ class _FusedQuantMixin:
             weight, bias = self.temp_weight, self.temp_bias
         else:
             weight, bias = self.weight, (self.bias if hasattr(self, "bias") else None)
-        stash = {}
+        # integer side channel for the int8 fprop of the linears that read y (ops.IntCodes), when they can use it
+        stash = {"want_int": True} if (lin.use_temporary_parameter and lin.int_fprop_eligible(x.dtype)) else {}
         y, res = ops.NormQuantFn.apply(x, weight, bias, eps, is_ln, q.n_bits, stash)
         q.scale, q.round_zero_point = stash["scale"], stash["zp"]
+        if stash.get("int") is not None:
+            y._oq_int = stash["int"]
         return y, res, stash.get("sib")
 
 

@@ -113,7 +113,10 @@ class FakeQuantFn(torch.autograd.Function):
         rows = w.numel() // cols
         nseg = rows * ((cols + seg - 1) // seg)          # a ragged last segment is zero-padded inside the kernel
         ws_out = None
-        if isinstance(out, (tuple, list)):
+        dest = None
+        if isinstance(out, WeightDest):
+            dest, ws_out, out = out, out.wshift, out.y
+        elif isinstance(out, (tuple, list)):
             out, ws_out = out
         if out is not None:
             # caller-provided destination (a row block of a buffer that stacks sibling weights, see stacked_rows)
@@ -122,8 +125,25 @@ class FakeQuantFn(torch.autograd.Function):
             y = out
         else:
             y = torch.empty(w.shape, dtype=out_dtype, device=w.device)
-        scale = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
-        zp = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
+        if dest is not None and dest.scale is not None:
+            scale, zp = dest.scale, dest.zp              # row blocks of vectors that stack the siblings' (block_common._weight_slabs)
+            if tuple(scale.shape) != (nseg, 1) or tuple(zp.shape) != (nseg, 1) or scale.dtype != torch.float32:
+                raise C.OQError("FakeQuantFn: scale / zp destinations must be float32 [segments, 1]")
+        else:
+            scale = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
+            zp = torch.empty((nseg, 1), dtype=torch.float32, device=w.device)
+        # integer side channel (IntCodes): asked for through stash["want_int"], produced when the kernels that take this
+        # problem can (whole-row segments, grids of at most 8 bits)
+        codes = csum = None
+        if stash is not None and stash.get("want_int") and int_codes_supported(cols, seg, nbits, not (
+                col_mul is None and row_div is None and row_mul is None and shift is None)):
+            if dest is not None and dest.codes is not None:
+                codes, csum = dest.codes, dest.csum
+                if tuple(codes.shape) != (rows, cols) or codes.dtype != torch.int8 or tuple(csum.shape) != (rows,):
+                    raise C.OQError("FakeQuantFn: codes / csum destinations must be int8 [rows, cols] / float32 [rows]")
+            else:
+                codes = torch.empty((rows, cols), dtype=torch.int8, device=w.device)
+                csum = torch.empty((rows,), dtype=torch.float32, device=w.device)
         xmin = torch.empty((nseg,), dtype=torch.float32, device=w.device)     # consumed by the backward kernel
         xmax = torch.empty((nseg,), dtype=torch.float32, device=w.device)
         wshift = None
@@ -134,17 +154,20 @@ class FakeQuantFn(torch.autograd.Function):
         cm, rd, rm, sh, u, l = (_f32(t) for t in (col_mul, row_div, row_mul, shift, up, low))
         fargs = (C.ptr(w), C.dt(w), rows, cols, seg, nbits, int(symmetric),
                  C.fptr(cm), C.fptr(rd), C.fptr(rm), C.fptr(sh), C.fptr(u), C.fptr(l),
-                 C.ptr(y), C._DT[out_dtype], C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.fptr(wshift))
+                 C.ptr(y), C._DT[out_dtype], C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.fptr(wshift),
+                 C.ptr(codes), C.fptr(csum))
         batch = WeightQuantBatch.active
         ctx.batch = None
         if batch is not None and batch.takes(w, cols, seg, col_mul, row_div, row_mul, shift):
             # launched with its siblings when the `with` block ends (one multi-matrix launch); the outputs are not read before
-            batch.add_forward(fargs, (w, cm, rd, rm, sh, u, l, y, scale, zp, xmin, xmax, wshift))
+            batch.add_forward(fargs, (w, cm, rd, rm, sh, u, l, y, scale, zp, xmin, xmax, wshift, codes, csum))
             ctx.batch = batch
         else:
             C.call("oq_fakequant_fwd", *fargs, C.stream())
         if stash is not None:
             stash["scale"], stash["zp"] = scale, zp
+            if codes is not None:
+                stash["int"] = IntCodes(codes, scale.view(-1), zp.view(-1), csum, nbits)
         ctx.save_for_backward(w, cm, rd, rm, sh, u, l, xmin, xmax)
         ctx.cfg = (rows, cols, seg, nbits, int(symmetric))
         # gradient routing set up by optim.BlockOptimizer: single-use learnables (LWC bounds) get their gradient
@@ -306,9 +329,10 @@ def gemm(a, b, c, M, N, K, lda, ldb, ldc, a_kc, b_kc, bias=None, alpha=1.0, batc
 
 class IntCodes:
     """Integer side of a fake-quantised tensor, written by the quantiser kernels next to their bf16 / f32 output:
-    codes [rows, cols] int8 = grid code - 2^(nbits-1); scale, zp [rows] (the quantiser's scale / rounded zero-point);
-    csum [rows] = sum of the stored codes of the row (float, exact).  With it  dequant[r][k] = (codes[r][k] + 2^(nbits-1) -
-    zp[r]) * scale[r]  exactly, and a Linear whose two operands carry IntCodes runs its fprop on the int8 MFMA (gemm_i8)."""
+    codes [rows, cols] int8 = the grid codes 0 .. 2^nbits - 1 (8-bit grids: code - 128); scale, zp [rows] (the quantiser's
+    scale / rounded zero-point); csum [rows] = sum of the stored codes of the row (float, exact).  With it
+    dequant[r][k] = (code[r][k] - zp[r]) * scale[r]  exactly, and a Linear whose two operands carry IntCodes runs its fprop
+    on the int8 MFMA (gemm_i8)."""
     __slots__ = ("codes", "scale", "zp", "csum", "nbits")
 
     def __init__(self, codes, scale, zp, csum, nbits):
@@ -317,6 +341,47 @@ class IntCodes:
     def rows(self, lo, hi):
         """The same for the row block [lo, hi) (sibling weights stacked in one buffer)."""
         return IntCodes(self.codes[lo:hi], self.scale[lo:hi], self.zp[lo:hi], self.csum[lo:hi], self.nbits)
+
+
+class WeightDest:
+    """Caller-provided destinations of a weight quantiser's outputs: row blocks of buffers that stack sibling weights
+    (block_common._weight_slabs), so that q | k | v and gate | up -- values, integer codes and per-row vectors -- are one
+    operand of ONE GEMM per direction.  Any field may be None (allocated by the quantiser then)."""
+    __slots__ = ("y", "wshift", "codes", "scale", "zp", "csum")
+
+    def __init__(self, y=None, wshift=None, codes=None, scale=None, zp=None, csum=None):
+        self.y, self.wshift, self.codes, self.scale, self.zp, self.csum = y, wshift, codes, scale, zp, csum
+
+
+def int_fprop_on():
+    """Integer-exact fprop of the fake-quant Linears (oq_gemm_i8) in the bf16 production mode.  OQ_INT_FPROP=0: A/B switch
+    back to bf16 operands."""
+    return os.environ.get("OQ_INT_FPROP", "1") != "0"
+
+
+def int_pre_dtype(act_dtype):
+    """dtype of a projection output that feeds a fused producer -> quantiser kernel (q | k | v -> RoPE -> head quantiser,
+    gate | up -> silu * up -> down_proj input quantiser) on the integer path: float32 by default, so that the exact GEMM
+    result is not rounded to bf16 in front of the next 4-bit rounding decision.  OQ_INT_PRE_F32=0: the activation dtype."""
+    return torch.float32 if os.environ.get("OQ_INT_PRE_F32", "1") != "0" else act_dtype
+
+
+def int_codes_supported(cols, seg, nbits, let):
+    return bool(C.size_call("oq_fakequant_codes_supported", int(cols), int(seg), int(nbits), int(bool(let))))
+
+
+def stacked_int(ints):
+    """IntCodes of sibling weights whose codes and per-row vectors lie back to back (block_common._weight_slabs) -> the
+    IntCodes of the stacked operand, else None."""
+    if any(i is None for i in ints) or len({i.nbits for i in ints}) != 1:
+        return None
+    codes = stacked_rows([i.codes for i in ints])
+    if codes is None:
+        return None
+    vecs = [stacked_vectors([getattr(i, f) for i in ints]) for f in ("scale", "zp", "csum")]
+    if any(v is None or v is False for v in vecs):
+        return None
+    return IntCodes(codes, vecs[0], vecs[1], vecs[2], ints[0].nbits)
 
 
 def gemm_i8(a, b, c, bias=None, addend=None):
@@ -366,7 +431,7 @@ class LinearFn(torch.autograd.Function):
     models/int_llama_layer.py:246,264 is folded into the GEMM's store) with dgrad / wgrad / bias-grad kernels."""
 
     @staticmethod
-    def forward(ctx, x, wq, bias, residual=None, sib=None):
+    def forward(ctx, x, wq, bias, residual=None, sib=None, xint=None, wint=None):
         ctx.sib = sib
         x2 = x.contiguous().view(-1, x.shape[-1])
         wq = wq.contiguous()
@@ -381,7 +446,12 @@ class LinearFn(torch.autograd.Function):
             if residual.dtype != x2.dtype or residual.numel() != T * N:
                 raise C.OQError("LinearFn: residual must have the output's dtype and size")
             res2 = residual.contiguous().view(T, N)
-        gemm(x2, wq, y, T, N, K, K, K, N, True, True, bias=b32, addend=res2)
+        if xint is not None and wint is not None and tuple(xint.codes.shape) == (T, K) and tuple(wint.codes.shape) == (N, K):
+            # both operands are on quantiser grids: the fprop contracts their integer codes exactly (int8 MFMA); x2 / wq -- the
+            # same values rounded to bf16 -- are only the backward's operands
+            gemm_i8(xint, wint, y, bias=b32, addend=res2)
+        else:
+            gemm(x2, wq, y, T, N, K, K, K, N, True, True, bias=b32, addend=res2)
         ctx.save_for_backward(x2, wq)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -412,7 +482,7 @@ class LinearFn(torch.autograd.Function):
             ws = torch.empty(ws_n, dtype=torch.float32, device=gy2.device)
             C.call("oq_colsum", C.ptr(gy2), C.dt(gy2), T, N, C.fptr(gb), C.fptr(ws), ws_n, C.stream())
         gres = gy if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres, None
+        return gx, gw, gb, gres, None, None, None
 
 
 def rope_quant_supported(dtype, hd):
@@ -497,7 +567,7 @@ class QKVRopeQuantFn(torch.autograd.Function):
     x [bs, T, K]; returns q [bs, T, nhq, hd], k, v [bs, T, nhk|nhv, hd]."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, cos, sin, nbits, hd, stashes, sib=None):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, cos, sin, nbits, hd, stashes, sib=None, xint=None, wints=None):
         ctx.sib = sib
         x2 = x.contiguous().view(-1, x.shape[-1])
         ws = [w.contiguous() for w in (wq, wk, wv)]
@@ -508,12 +578,18 @@ class QKVRopeQuantFn(torch.autograd.Function):
         for w in ws:
             if w.dtype != x2.dtype:
                 raise C.OQError(f"QKVRopeQuantFn: weight dtype {w.dtype} != activation dtype {x2.dtype}")
-        pre = torch.empty((rows, Ntot), dtype=x2.dtype, device=x2.device)
         offs = [0, Ns[0], Ns[0] + Ns[1]]
         wall = stacked_rows(ws)
         ball = stacked_vectors(bs_) if wall is not None else False
         ctx.stacked = wall is not None and ball is not False
-        if ctx.stacked:
+        wint = stacked_int(list(wints)) if (ctx.stacked and xint is not None and wints is not None) else None
+        if wint is not None and (tuple(xint.codes.shape) != (rows, K) or tuple(wint.codes.shape) != (Ntot, K)):
+            wint = None
+        pre = torch.empty((rows, Ntot), dtype=int_pre_dtype(x2.dtype) if wint is not None else x2.dtype, device=x2.device)
+        if wint is not None:
+            # integer-exact projections (oq_gemm_i8); the result reaches RoPE and the head quantisers in fp32
+            gemm_i8(xint, wint, pre, bias=ball)
+        elif ctx.stacked:
             # the three fake-quant weights are row blocks of one buffer: ONE GEMM with N = Nq + Nk + Nv
             gemm(x2, wall, pre, rows, Ntot, K, K, K, Ntot, True, True, bias=ball)
         else:
@@ -609,7 +685,7 @@ class QKVRopeQuantFn(torch.autograd.Function):
             for i, (N, off) in enumerate(zip(Ns, offs)):
                 if has_bias[i] and need[2 + 2 * i]:
                     gbs[i] = gb[off:off + N]
-        return (gx, gws[0], gbs[0], gws[1], gbs[1], gws[2], gbs[2], None, None, None, None, None, None)
+        return (gx, gws[0], gbs[0], gws[1], gbs[1], gws[2], gbs[2], None, None, None, None, None, None, None, None)
 
 
 class SiblingLinearFn(torch.autograd.Function):
@@ -841,11 +917,18 @@ class NormQuantFn(torch.autograd.Function):
         y = torch.empty_like(x)
         rstd, scale, zp, xmin, xmax = (torch.empty((rows, 1), dtype=torch.float32, device=x.device) for _ in range(5))
         mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if is_ln else None
+        codes = csum = None
+        if stash is not None and stash.get("want_int") and int(nbits) <= 8:
+            codes = torch.empty((rows, cols), dtype=torch.int8, device=x.device)
+            csum = torch.empty((rows,), dtype=torch.float32, device=x.device)
         C.call("oq_norm_quant_fwd", C.ptr(x), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), float(eps), int(is_ln), int(nbits),
-               C.ptr(y), C.fptr(rstd), C.fptr(mean), C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
+               C.ptr(y), C.dt(y), C.fptr(rstd), C.fptr(mean), C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax),
+               C.ptr(codes), C.fptr(csum), C.stream())
         ctx.sib = None
         if stash is not None:
             stash["scale"], stash["zp"] = scale, zp
+            if codes is not None:
+                stash["int"] = IntCodes(codes, scale.view(-1), zp.view(-1), csum, int(nbits))
             if not os.environ.get("OQ_NO_SIBLING_GRADS"):
                 ctx.sib = stash["sib"] = SiblingGrads()       # hand this to every consumer of y (see SiblingGrads)
         ctx.save_for_backward(x, w32, b32, rstd, mean, xmin, xmax)
@@ -879,7 +962,7 @@ class NormQuantFn(torch.autograd.Function):
         gb = torch.empty((cols,), dtype=torch.float32, device=x.device) if (has_b and ctx.needs_input_grad[2]) else None
         ws_n = C.size_call("oq_norm_quant_bwd_workspace", rows, cols)
         ws = torch.empty((ws_n,), dtype=torch.float32, device=x.device)
-        C.call("oq_norm_quant_bwd", C.ptr(x), C.ptr(gy), C.ptr(g2), C.ptr(g3), C.dt(x), rows, cols, C.fptr(w32), C.fptr(b32), C.fptr(rstd), C.fptr(mean),
+        C.call("oq_norm_quant_bwd", C.ptr(x), C.ptr(gy), C.ptr(g2), C.ptr(g3), C.dt(x), C.dt(gy), rows, cols, C.fptr(w32), C.fptr(b32), C.fptr(rstd), C.fptr(mean),
                int(is_ln), nbits, C.fptr(xmin), C.fptr(xmax), C.ptr(gx), C.fptr(gw), C.fptr(gb), C.ptr(gpass), C.fptr(ws), ws_n,
                C.stream())
         return gx, (gw if ctx.needs_input_grad[1] else None), gb, None, None, None, None
@@ -950,7 +1033,7 @@ class StackedGateUpFn(torch.autograd.Function):
     models/int_llama_layer.py:44-45 + quantize/int_linear.py:48-65."""
 
     @staticmethod
-    def forward(ctx, x, wg, bg, wu, bu, nbits, stash, sib=None):
+    def forward(ctx, x, wg, bg, wu, bu, nbits, stash, sib=None, xint=None, wints=None):
         ctx.sib = sib
         x2 = x.contiguous().view(-1, x.shape[-1])
         rows, K = x2.shape
@@ -961,17 +1044,31 @@ class StackedGateUpFn(torch.autograd.Function):
         if wall.dtype != x2.dtype:
             raise C.OQError(f"StackedGateUpFn: weight dtype {wall.dtype} != activation dtype {x2.dtype}")
         I = wg.shape[0]
-        es = x2.element_size()
-        pre = torch.empty((rows, 2 * I), dtype=x2.dtype, device=x2.device)
-        gemm(x2, wall, pre, rows, 2 * I, K, K, K, 2 * I, True, True, bias=ball)
-        y = torch.empty((rows, I), dtype=x2.dtype, device=x2.device)
         nbits = int(nbits or 0)
+        wint = stacked_int(list(wints)) if (xint is not None and wints is not None) else None
+        if wint is not None and (tuple(xint.codes.shape) != (rows, K) or tuple(wint.codes.shape) != (2 * I, K)):
+            wint = None
+        # integer path: the exact projection result stays fp32 when a quantiser reads it next (silu * up -> down_proj input)
+        pre_dtype = int_pre_dtype(x2.dtype) if (wint is not None and nbits) else x2.dtype
+        pre = torch.empty((rows, 2 * I), dtype=pre_dtype, device=x2.device)
+        es = pre.element_size()
+        if wint is not None:
+            gemm_i8(xint, wint, pre, bias=ball)
+        else:
+            gemm(x2, wall, pre, rows, 2 * I, K, K, K, 2 * I, True, True, bias=ball)
+        y = torch.empty((rows, I), dtype=x2.dtype, device=x2.device)
         if nbits:
             scale, zp, xmin, xmax = (torch.empty((rows, 1), dtype=torch.float32, device=x2.device) for _ in range(4))
+            codes = csum = None
+            if stash is not None and stash.get("want_int") and nbits <= 8:
+                codes = torch.empty((rows, I), dtype=torch.int8, device=x2.device)
+                csum = torch.empty((rows,), dtype=torch.float32, device=x2.device)
             C.call("oq_silu_mul_quant_fwd", pre.data_ptr(), pre.data_ptr() + I * es, C.dt(pre), rows, I, 2 * I, nbits, C.ptr(y),
-                   C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
+                   C.dt(y), C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.ptr(codes), C.fptr(csum), C.stream())
             if stash is not None:
                 stash["scale"], stash["zp"] = scale, zp
+                if codes is not None:
+                    stash["int"] = IntCodes(codes, scale.view(-1), zp.view(-1), csum, nbits)
             ctx.save_for_backward(x2, wg, wu, pre, xmin, xmax)
         else:
             C.call("oq_silu_mul_fwd_2d", pre.data_ptr(), pre.data_ptr() + I * es, C.ptr(y), C.dt(pre), rows, I, 2 * I, C.stream())
@@ -994,8 +1091,8 @@ class StackedGateUpFn(torch.autograd.Function):
             gy = gy.to(x2.dtype)
         gpre = torch.empty((rows, 2 * I), dtype=x2.dtype, device=x2.device)
         if nbits:
-            C.call("oq_silu_mul_quant_bwd", pre.data_ptr(), pre.data_ptr() + I * es, C.ptr(gy), C.dt(pre), rows, I, 2 * I, nbits,
-                   C.fptr(xmin), C.fptr(xmax), gpre.data_ptr(), gpre.data_ptr() + I * es, C.stream())
+            C.call("oq_silu_mul_quant_bwd", pre.data_ptr(), pre.data_ptr() + I * pre.element_size(), C.ptr(gy), C.dt(pre), C.dt(gy),
+                   rows, I, 2 * I, nbits, C.fptr(xmin), C.fptr(xmax), gpre.data_ptr(), gpre.data_ptr() + I * es, C.stream())
         else:
             C.call("oq_silu_mul_bwd_2d", pre.data_ptr(), pre.data_ptr() + I * es, C.ptr(gy), gpre.data_ptr(),
                    gpre.data_ptr() + I * es, C.dt(pre), rows, I, 2 * I, C.stream())
@@ -1018,7 +1115,7 @@ class StackedGateUpFn(torch.autograd.Function):
             wsb = torch.empty(ws_n, dtype=torch.float32, device=x2.device)
             C.call("oq_colsum", C.ptr(gpre), C.dt(gpre), rows, 2 * I, C.fptr(gb), C.fptr(wsb), ws_n, C.stream())
             gbg, gbu = (gb[:I] if need[2] else None), (gb[I:] if need[4] else None)
-        return gx, gwg, gbg, gwu, gbu, None, None, None
+        return gx, gwg, gbg, gwu, gbu, None, None, None, None, None
 
 
 class SiluMulQuantFn(torch.autograd.Function):
@@ -1033,10 +1130,16 @@ class SiluMulQuantFn(torch.autograd.Function):
         rows = gate.numel() // cols
         y = torch.empty_like(gate)
         scale, zp, xmin, xmax = (torch.empty((rows, 1), dtype=torch.float32, device=gate.device) for _ in range(4))
-        C.call("oq_silu_mul_quant_fwd", C.ptr(gate), C.ptr(up), C.dt(gate), rows, cols, 0, int(nbits), C.ptr(y),
-               C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
+        codes = csum = None
+        if stash is not None and stash.get("want_int") and int(nbits) <= 8:
+            codes = torch.empty((rows, cols), dtype=torch.int8, device=gate.device)
+            csum = torch.empty((rows,), dtype=torch.float32, device=gate.device)
+        C.call("oq_silu_mul_quant_fwd", C.ptr(gate), C.ptr(up), C.dt(gate), rows, cols, 0, int(nbits), C.ptr(y), C.dt(y),
+               C.fptr(scale), C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.ptr(codes), C.fptr(csum), C.stream())
         if stash is not None:
             stash["scale"], stash["zp"] = scale, zp
+            if codes is not None:
+                stash["int"] = IntCodes(codes, scale.view(-1), zp.view(-1), csum, int(nbits))
         ctx.save_for_backward(gate, up, xmin, xmax)
         ctx.nbits = int(nbits)
         return y
@@ -1050,7 +1153,7 @@ class SiluMulQuantFn(torch.autograd.Function):
         cols = gate.shape[-1]
         rows = gate.numel() // cols
         gg, gu = torch.empty_like(gate), torch.empty_like(up)
-        C.call("oq_silu_mul_quant_bwd", C.ptr(gate), C.ptr(up), C.ptr(gy), C.dt(gate), rows, cols, 0, ctx.nbits,
+        C.call("oq_silu_mul_quant_bwd", C.ptr(gate), C.ptr(up), C.ptr(gy), C.dt(gate), C.dt(gy), rows, cols, 0, ctx.nbits,
                C.fptr(xmin), C.fptr(xmax), C.ptr(gg), C.ptr(gu), C.stream())
         return gg, gu, None, None
 

@@ -68,7 +68,7 @@ class UniformAffineQuantizer(nn.Module):
     def _identity(self):
         return self.n_bits >= 16 or not self.enable
 
-    def quantize(self, x, out_dtype=None, col_mul=None, row_div=None, row_mul=None, shift=None, out=None):
+    def quantize(self, x, out_dtype=None, col_mul=None, row_div=None, row_mul=None, shift=None, out=None, want_int=False):
         """Dynamic calibration + fake quant in ONE kernel, optionally fused with the LET weight transform
         x' = ((x*col_mul)/row_div)*row_mul and the by-product x @ shift.  Sets self.scale/round_zero_point.
 
@@ -78,15 +78,18 @@ class UniformAffineQuantizer(nn.Module):
         A ragged last group (in_features % group_size != 0, symmetric only as in the reference, :64-69) is zero-padded
         inside the kernel exactly like :85-87 / :125-128.
         out: destination tensor of the fake-quantised values (block_common stacks sibling weights in one buffer); ignored
-        by the identity branch."""
+        by the identity branch.
+        want_int: also produce the integer side channel (ops.IntCodes: the grid codes as int8 + per-row code sums) when the
+        kernels can; it is attached to the returned tensor as `_oq_int` and kept in `self.int_codes` (None when not produced)."""
         let = not (col_mul is None and row_div is None and row_mul is None and shift is None)
+        self.int_codes = None
         if self._identity():
             self.scale = self.round_zero_point = None
             if not let:
                 return ops.cast(x, out_dtype) if out_dtype is not None else x
             res = ops.fake_quant(x, 16, x.shape[-1], None, None, False, out_dtype, None, col_mul, row_div, row_mul, shift)
             return res
-        stash = {}
+        stash = {"want_int": True} if (want_int and self.n_bits <= 8 and x.dim() >= 2) else {}
         up = self.upbound_factor if self.lwc else None
         low = self.lowbound_factor if self.lwc else None
         seg = self._segment(x)
@@ -95,6 +98,11 @@ class UniformAffineQuantizer(nn.Module):
         res = ops.fake_quant(x, self.n_bits, seg, up, low, self.symmetric, out_dtype, stash,
                              col_mul, row_div, row_mul, shift, out=out)
         self.scale, self.round_zero_point = stash["scale"], stash["zp"]
+        ic = stash.get("int")
+        if ic is not None:
+            self.int_codes = ic
+            y = res[0] if isinstance(res, tuple) else res
+            y._oq_int = ic             # consumers (linear._hip_linear, the fused block nodes) pick it up from the tensor
         return res
 
     def forward(self, x: torch.Tensor):

@@ -9,7 +9,7 @@ DEV = "cuda:0"
 
 
 def _side(rows, K, bits, gen, zp_range=None):
-    off = 1 << (bits - 1)
+    off = 128 if bits == 8 else 0                                               # the quantisers' storage convention
     q = torch.randint(0, 1 << bits, (rows, K), generator=gen)                   # grid codes
     codes = (q - off).to(torch.int8)
     scale = (torch.rand(rows, generator=gen) * 0.1 + 0.01).float()
@@ -37,7 +37,7 @@ def test_gemm_i8_exact(M, N, K, abits, wbits, out_dtype):
     W = ops.IntCodes(cw.to(DEV), sw.to(DEV), zw.to(DEV), csw.to(DEV), wbits)
     # (1) raw integer accumulators: scales 1, zero-points at the offset (z' = 0), no bias -> the output IS sum codes_a * codes_b
     one = lambda n: torch.ones(n, device=DEV)
-    offa, offw = float(1 << (abits - 1)), float(1 << (wbits - 1))
+    offa, offw = (128.0 if abits == 8 else 0.0), (128.0 if wbits == 8 else 0.0)
     A1 = ops.IntCodes(A.codes, one(M), torch.full((M,), offa, device=DEV), A.csum, abits)
     W1 = ops.IntCodes(W.codes, one(N), torch.full((N,), offw, device=DEV), W.csum, wbits)
     c = torch.empty(M, N, dtype=torch.float32, device=DEV)

@@ -29,7 +29,7 @@ def bwd(cm_, rd_, sh_, gws_, gcm_, gsh_, grd_, x=W, g=G, gx=None):
            C.ptr(g), C.dt(g), P(gws_), P(g_up), P(g_low), C.ptr(gx), C.dt(g), P(gcm_), P(gsh_), P(grd_), None, P(ws), ws_n, st)
 def fwd(cm_, rd_, sh_, wsh_):
     C.call("oq_fakequant_fwd", C.ptr(W), C.dt(W), rows, cols, cols, 4, 0, P(cm_), P(rd_), None, P(sh_), P(up), P(low),
-           C.ptr(y), 2, P(sc), P(zp), P(xmn), P(xmx), P(wsh_), st)
+           C.ptr(y), 2, P(sc), P(zp), P(xmn), P(xmx), P(wsh_), None, None, st)
 fwd(cm, rd, sh, wsh)
 print("bwd LET full        ", timeit(lambda: bwd(cm, rd, sh, gws, g_cm, g_sh, g_rd)))
 print("bwd LET no colgrads ", timeit(lambda: bwd(cm, rd, None, None, None, None, g_rd)))

@@ -49,10 +49,14 @@ def case(name, rows, cols, let, lwc, act, nbytes_f, nbytes_b):
     sc, zp, wsh = (torch.empty(rows, device=dev) for _ in range(3))
     xmn, xmx = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
     st = C.stream()
+    want_codes = os.environ.get("OQ_MB_CODES", "0") != "0"       # OQ_MB_CODES=1: also write the integer side channel
+    codes_t = torch.empty(rows, cols, device=dev, dtype=torch.int8) if want_codes else None
+    csum_t = torch.empty(rows, device=dev) if want_codes else None
+    CODES, CSUM = C.ptr(codes_t), P(csum_t)
 
     def fwd():
         C.call("oq_fakequant_fwd", C.ptr(W), C.dt(W), rows, cols, cols, 4, 0, P(cm), P(rd), None, P(sh), P(up), P(low),
-               C.ptr(y), 2, P(sc), P(zp), P(xmn), P(xmx), P(wsh if let else None), st)
+               C.ptr(y), 2, P(sc), P(zp), P(xmn), P(xmx), P(wsh if let else None), CODES, CSUM, st)
 
     def bwd():
         ws_n = C.size_call("oq_fakequant_bwd_workspace", rows, cols)
