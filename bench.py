@@ -30,6 +30,9 @@ sys.path.insert(0, ROOT)
 CONFIGS = {
     # name: (arch, wbits, abits, group, lwc, let, let_lr, alpha, aug_loss)
     "llama-7b-w4a4": ("llama-7b", 4, 4, None, True, True, 5e-3, 0.5, False),
+    # the reference's own recipe for this model (scripts/llama/llama-7b/w4a4.sh:4 adds --aug_loss: a second MSE term against the
+    # teacher output of the STUDENT input, quantize/omniquant.py:168-171,221-222)
+    "llama-7b-w4a4-aug": ("llama-7b", 4, 4, None, True, True, 5e-3, 0.5, True),
     "llama-7b-w3a16g128": ("llama-7b", 3, 16, 128, True, False, 5e-3, 0.5, False),
     "llama-2-13b-w4a4": ("llama-2-13b", 4, 4, None, True, True, 1e-3, 0.75, False),
     "llama-2-70b-w2a16g64": ("llama-2-70b", 2, 16, 64, True, False, 5e-3, 0.5, False),
@@ -37,6 +40,7 @@ CONFIGS = {
 }
 WORKLOAD = {
     "llama-7b-w4a4": "LLaMA-7B W4A4 --lwc --let, 128x2048 calib, one decoder block per GPU (BASELINE configs[2])",
+    "llama-7b-w4a4-aug": "LLaMA-7B W4A4 --lwc --let --aug_loss (scripts/llama/llama-7b/w4a4.sh), 128x2048 calib, one decoder block per GPU",
     "llama-7b-w3a16g128": "LLaMA-7B W3A16g128 --lwc, 128x2048 calib, one decoder block per GPU (BASELINE configs[1])",
     "llama-2-13b-w4a4": "LLaMA-2-13B W4A4 --lwc --let, 128x2048 calib, one decoder block per GPU",
     "llama-2-70b-w2a16g64": "LLaMA-2-70B W2A16g64 --lwc, 128x2048 calib, one decoder block per GPU",
@@ -94,75 +98,154 @@ def build_block(name, rank, dev, nsamples, seed=0):
     return cfg, args, q, opt, runner, quant_inps, fp_inps
 
 
-def gemm_roofline(runner, quant_inps, fp_inps, cfg, n_prof=3):
-    """Per-launch duration of the MFMA GEMM kernel, measured with HIP events on the launch stream while the real
-    sample-step runs eagerly (same data, same cache state as the timed loop)."""
-    from omniquant_amd import ops
-    import inspect
+_DT_SIZE = {0: 4, 1: 2, 2: 2}      # OQ_F32, OQ_F16, OQ_BF16 (include/oq_hip.h)
+
+
+def _hbm_bytes(name, a):
+    """Algorithmic HBM bytes of one call of a quantiser-class entry point (what the kernel must read and
+    write once), from its C-ABI arguments.  None for entry points that are not priced."""
+    import ctypes
+    from omniquant_amd import _capi as C
+    sz = _DT_SIZE
+    if name == "oq_fakequant_fwd":
+        return a[2] * a[3] * (sz[a[1]] + sz[a[14]] + (1 if a[20] else 0))
+    if name == "oq_fakequant_bwd":
+        return a[2] * a[3] * (sz[a[1]] + sz[a[16]] + (sz[a[21]] if a[20] else 0))
+    if name == "oq_fakequant_fwd_multi":
+        arr = (C.FakeQuantFwdArgs * a[1]).from_address(a[0])
+        return sum(t.rows * t.cols * (sz[t.w_dtype] + sz[t.y_dtype] + (1 if t.codes else 0)) for t in arr)
+    if name == "oq_fakequant_bwd_multi":
+        arr = (C.FakeQuantBwdArgs * a[1]).from_address(a[0])
+        return sum(t.rows * t.cols * (sz[t.w_dtype] + sz[t.g_dtype] + (sz[t.gx_dtype] if t.gx else 0)) for t in arr)
+    if name == "oq_norm_quant_fwd":
+        return a[2] * a[3] * (sz[a[1]] + sz[a[10]] + (1 if a[17] else 0))
+    if name == "oq_norm_quant_bwd":
+        n_g = 1 + (1 if a[2] else 0) + (1 if a[3] else 0) + (1 if a[19] else 0)
+        return a[6] * a[7] * (sz[a[4]] + sz[a[5]] * (n_g + 1))
+    if name == "oq_silu_mul_quant_fwd":
+        return a[3] * a[4] * (2 * sz[a[2]] + sz[a[8]] + (1 if a[13] else 0))
+    if name == "oq_silu_mul_quant_bwd":
+        return a[5] * a[6] * (2 * sz[a[3]] + 3 * sz[a[4]])
+    if name == "oq_qkv_rope_quant_fwd":
+        return a[2] * (a[4] + a[5] + a[6]) * a[7] * (sz[a[1]] + sz[a[14]])
+    if name == "oq_qkv_rope_quant_bwd":
+        return a[2] * (a[4] + a[5] + a[6]) * a[7] * (sz[a[1]] + 2 * sz[a[16]])
+    return None
+
+
+KERNEL_OF = {"oq_fakequant_fwd_multi": "letq_fwd_multi_kernel (LET + LWC weight quantiser, several matrices)",
+             "oq_fakequant_bwd_multi": "letq_bwd_multi_kernel (its backward: reduces dW to LWC / LET gradients)",
+             "oq_fakequant_fwd": "rowq_fwd_kernel / letq_fwd_kernel (weight or per-token quantiser)",
+             "oq_fakequant_bwd": "rowq_bwd_kernel / letq_bwd_kernel",
+             "oq_norm_quant_fwd": "normq_fwd_kernel (RMSNorm -> per-token quantiser)", "oq_norm_quant_bwd": "normq_bwd_kernel",
+             "oq_silu_mul_quant_fwd": "rowq_fwd_kernel<PRO=1> (silu * up -> per-token quantiser)",
+             "oq_silu_mul_quant_bwd": "rowq_bwd_kernel<PRO=1>", "oq_qkv_rope_quant_fwd": "ropeq_fwd_kernel (RoPE -> head quantisers)",
+             "oq_qkv_rope_quant_bwd": "ropeq_bwd_kernel"}
+
+
+def kernel_rooflines(runner, quant_inps, fp_inps, cfg, n_prof=3):
+    """Per-launch durations measured with HIP events on the launch stream (every C-ABI call is bracketed) while the real
+    sample-step runs eagerly -- same data, same cache state as the timed loop.  Returns the MFMA GEMM figures (bf16 and int8
+    launches of the fake-quant linears) and the HBM-class quantiser kernels' achieved bandwidth."""
+    from omniquant_amd import _capi as C
     rec = []
-    orig = ops.gemm
-    sig = inspect.signature(orig)
+    orig = C.call
 
-    def timed(a, b, c, M, N, K, *rest, **kw):
+    def timed(name, *args):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(torch.cuda.current_stream())
-        orig(a, b, c, M, N, K, *rest, **kw)
-        e1.record(torch.cuda.current_stream())
-        ba = sig.bind(a, b, c, M, N, K, *rest, **kw)
-        ba.apply_defaults()
-        g = ba.arguments
-        nb = g["batch_o"] * g["batch_i"]
-        rec.append((e0, e1, 2.0 * M * N * K * nb, (M, N, K, int(g["a_kc"]), int(g["b_kc"]), nb, int(g["tri"]))))
+        st = torch.cuda.current_stream()
+        nbytes = _hbm_bytes(name, args)      # (the multi-matrix entry points pass a struct array that lives only during the call)
+        e0.record(st)
+        orig(name, *args)
+        e1.record(st)
+        rec.append((name, e0, e1, args, nbytes))
 
+    # the eager step's host side is slower than its short kernels: without a head start the GPU idles between launches and an
+    # event pair would time the host.  A spin kernel in front of every profiled step lets the host queue the whole step first.
+    t_probe = time.perf_counter()
+    torch.cuda._sleep(20_000_000)
+    torch.cuda.synchronize()
+    spin = int(20_000_000 * 0.06 / max(time.perf_counter() - t_probe, 1e-4))      # ~60 ms
     runner.use_graph = False
-    ops.gemm = timed
+    C.call = timed
     try:
         for j in range(n_prof):
-            runner.run(quant_inps[j:j + 1], fp_inps[j:j + 1])
+            torch.cuda._sleep(spin)
+            runner.run(quant_inps[j:j + 1], fp_inps[j:j + 1], fp_inps[j:j + 1] if runner.t2 is not None else None)
         torch.cuda.synchronize()
     finally:
-        ops.gemm = orig
+        C.call = orig
         runner.use_graph = True
     H = cfg.hidden_size
-    lin = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, sh in rec
-           if sh[5] == 1 and (min(sh[:3]) >= 1024 or (sh[0] * sh[1] * sh[2] >= 2048 * H * H))]
+    lin, lin8, allg, hbm = [], [], 0.0, {}
+    shapes = []
+    for name, e0, e1, a, nbytes in rec:
+        dt = e0.elapsed_time(e1) * 1e-3
+        if name in ("oq_gemm", "oq_gemm_ws"):
+            M, N, K, nb, tri = a[5], a[6], a[7], a[16] * a[17], a[24]
+            allg += dt
+            shapes.append(((M, N, K, a[11], a[12], nb, tri, "bf16"), dt, 2.0 * M * N * K * nb))
+            if nb == 1 and (min(M, N, K) >= 1024 or M * N * K >= 2048 * H * H):
+                lin.append((dt, 2.0 * M * N * K))
+        elif name == "oq_gemm_i8":
+            M, N, K = a[11], a[12], a[13]
+            allg += dt
+            shapes.append(((M, N, K, 1, 1, 1, 0, "int8"), dt, 2.0 * M * N * K))
+            lin8.append((dt, 2.0 * M * N * K))
+        else:
+            b = nbytes
+            if b is not None:
+                h = hbm.setdefault(name, [0, 0.0, 0.0])
+                h[0] += 1; h[1] += dt; h[2] += float(b)
     if os.environ.get("OQ_BENCH_SHAPES"):
         import collections
         by = collections.OrderedDict()
-        for e0, e1, fl, sh in rec:
-            a = by.setdefault(sh, [0, 0.0, 0.0])
-            a[0] += 1; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += fl
+        for sh, t, fl in shapes:
+            acc = by.setdefault(sh, [0, 0.0, 0.0])
+            acc[0] += 1; acc[1] += t; acc[2] += fl
         for sh, (n, t, fl) in by.items():
             tri = {0: 1.0, 1: 0.5, 2: 0.5, 3: 0.5}.get(sh[6], 1.0)
-            print(f"[gemm] M={sh[0]:6d} N={sh[1]:6d} K={sh[2]:6d} a_kc={sh[3]} b_kc={sh[4]} batch={sh[5]:3d} tri={sh[6]} "
-                  f"n/step={n // n_prof:2d} avg={1e6 * t / n:8.1f} us  {fl * tri / t / 1e12:7.1f} TF/s", file=sys.stderr)
-    tot_t = sum(t for t, _ in lin)
-    tot_f = sum(f for _, f in lin)
-    n = len(lin)
-    all_t = sum(e0.elapsed_time(e1) * 1e-3 for e0, e1, _, _ in rec)
-    return dict(launches_per_step=n // n_prof, avg_launch_ms=1e3 * tot_t / max(n, 1), tflops=tot_f / tot_t / 1e12,
-                gemm_ms_per_step=1e3 * all_t / n_prof, linear_gemm_ms_per_step=1e3 * tot_t / n_prof)
+            print(f"[gemm] {sh[7]:4s} M={sh[0]:6d} N={sh[1]:6d} K={sh[2]:6d} a_kc={sh[3]} b_kc={sh[4]} batch={sh[5]:3d} tri={sh[6]} "
+                  f"n/step={n // n_prof:2d} avg={1e6 * t / n:8.1f} us  {fl * tri / t / 1e12:7.1f} T/s", file=sys.stderr)
+        for name, (n, t, b) in hbm.items():
+            print(f"[hbm]  {name:26s} n/step={n // n_prof:2d} avg={1e6 * t / n:8.1f} us  {b / t / 1e9:8.1f} GB/s", file=sys.stderr)
+
+    def agg(v):
+        t, f = sum(x for x, _ in v), sum(x for _, x in v)
+        return dict(launches_per_step=len(v) // n_prof, avg_launch_ms=1e3 * t / max(len(v), 1), tflops=(f / t / 1e12) if t else 0.0,
+                    ms_per_step=1e3 * t / n_prof, tflop_per_step=f / n_prof / 1e12)
+
+    out = dict(bf16=agg(lin), int8=agg(lin8) if lin8 else None, gemm_ms_per_step=1e3 * allg / n_prof, hbm=[])
+    for name, (n, t, b) in sorted(hbm.items(), key=lambda kv: -kv[1][1]):
+        out["hbm"].append(dict(entry=name, kernel=KERNEL_OF.get(name, name), launches_per_step=n // n_prof, us_per_step=1e6 * t / n_prof,
+                               avg_launch_us=1e6 * t / n, algorithmic_bytes_per_launch=b / n, achieved_gbs=b / t / 1e9,
+                               frac=b / t / 1e9 / HBM_PEAK_GBS))
+    return out
 
 
-PROFILE_COUNTERS = "r2_gemm_counters.json"
+PROFILE_COUNTERS = "r3_gemm_counters.json"
 ROOFLINE_KERNEL = "gemm_bf16_p3_kernel"
+MFMA_I8_PEAK_TOPS = 5000.0         # dense int8 = 2x bf16 (MI355X_MICROARCH.md, matrix-core table)
 
 
 def pmc_counters(name):
-    """rocprofv3 PMC results of the dominant kernel from the committed passes (profiles/README.md): HBM-side bytes per
-    launch (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950) and the MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CYCLES)).  Hardware counters
-    cannot be read from inside this process, so the numbers come from profiles/ -- and ONLY when that file was
-    collected for this config and for the kernel the run reports; otherwise both are null."""
+    """rocprofv3 PMC results of the dominant kernel from the COMMITTED passes (profiles/README.md): HBM-side bytes per launch
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+    and the MFMA-busy fraction.  Hardware counters cannot be read from inside this process: the numbers are NOT measured
+    by this run, so they are reported together with their provenance (file and the commit they were collected at), and
+    only when that file was collected for this config and for the kernel the run reports; otherwise null."""
     path = os.path.join(ROOT, "profiles", PROFILE_COUNTERS)
     try:
         with open(path) as f:
-            ent = json.load(f).get(name)
+            doc = json.load(f)
     except (OSError, ValueError):
-        return None, None
+        return None, None, None
+    ent = doc.get(name)
     if not ent or ent.get("kernel") != ROOFLINE_KERNEL:
-        return None, None
-    return ent.get("bytes_per_launch"), ent.get("mfma_busy_frac")
+        return None, None, None
+    src = {"file": "profiles/" + PROFILE_COUNTERS, "collected_at_commit": doc.get("_head"), "note": "rocprofv3 --pmc passes of this "
+           "command, committed; not measured by this run"}
+    return ent.get("bytes_per_launch"), ent.get("mfma_busy_frac"), src
 
 
 def cpu_baseline(name, n_steps=3, n_warm=1):
@@ -342,12 +425,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    aug = CONFIGS[a.config][8]          # --aug_loss: the step also reads fp_inps_2 (= the teacher output of the student input; with
+    fp2 = fp_inps if aug else None      # identical synthetic banks that is the same tensor as fp_inps)
     for j in range(a.warmup):
-        runner.run(quant_inps[j % n:j % n + 1], fp_inps[j % n:j % n + 1])
+        runner.run(quant_inps[j % n:j % n + 1], fp_inps[j % n:j % n + 1], fp2[j % n:j % n + 1] if aug else None)
     sync()
     t0 = time.perf_counter()
     for j in range(a.steps):
-        runner.run(quant_inps[j % n:j % n + 1], fp_inps[j % n:j % n + 1])
+        runner.run(quant_inps[j % n:j % n + 1], fp_inps[j % n:j % n + 1], fp2[j % n:j % n + 1] if aug else None)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -357,7 +442,7 @@ def main():
     loss = float(runner.loss)
     assert loss == loss, "NaN loss in the timed region"
 
-    roof = gemm_roofline(runner, quant_inps, fp_inps, cfg)
+    roof = kernel_rooflines(runner, quant_inps, fp_inps, cfg)
     e2e = None
     if not a.no_end_to_end and not a.config.startswith("opt"):
         del runner, opt, q
@@ -366,7 +451,8 @@ def main():
     if rank == 0:
         flops, P = linear_flops(cfg, SEQLEN)
         value = world * a.steps / dt
-        traffic, mfma_busy = pmc_counters(a.config)
+        traffic, mfma_busy, src = pmc_counters(a.config)
+        b16, i8 = roof["bf16"], roof["int8"]
         out = {
             "metric": "calibration_sample_steps_per_sec", "value": value, "unit": "sample-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
@@ -375,14 +461,34 @@ def main():
                        "calib_samples": n, "blocks_per_gpu": 1, "sharding": f"layers x{world}",
                        "n_ranks_seen": int(dist.get_world_size()) if dist is not None else 1,
                        "per_gpu_sample_steps_per_sec": value / world, "last_loss": loss,
-                       "linear_tflop_per_step": flops / 1e12},
-            "roofline": {"bound": "mfma", "kernel": ROOFLINE_KERNEL + " (fprop+dgrad+wgrad of the fake-quant linears)",
-                         "achieved": roof["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": roof["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "mfma_busy_frac": mfma_busy,
-                         "avg_launch_ms": roof["avg_launch_ms"], "launches_per_step": roof["launches_per_step"],
-                         "linear_gemm_ms_per_step": roof["linear_gemm_ms_per_step"],
+                       "linear_tflop_per_step": flops / 1e12,
+                       "fprop_arithmetic": "int8 codes on v_mfma_i32_16x16x64_i8 (exact), fp32 epilogue" if i8 else "bf16"},
+            # dominant kernel of the step: the bf16 MFMA GEMM (dgrad + wgrad of the fake-quant linears; + fprop when the integer
+            # path is off).  achieved = algorithmic flops of those launches / their summed HIP-event durations.
+            "roofline": {"bound": "mfma", "kernel": ROOFLINE_KERNEL + (" (dgrad+wgrad of the fake-quant linears)" if i8 else
+                                                                       " (fprop+dgrad+wgrad of the fake-quant linears)"),
+                         "achieved": b16["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": b16["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "mfma_busy_frac": mfma_busy,
+                         "traffic_and_busy_from_profile": src,
+                         "avg_launch_ms": b16["avg_launch_ms"], "launches_per_step": b16["launches_per_step"],
+                         "linear_gemm_ms_per_step": b16["ms_per_step"], "tflop_per_step": b16["tflop_per_step"],
                          "all_gemm_ms_per_step": roof["gemm_ms_per_step"]},
         }
+        if i8:
+            out["roofline_int8"] = {"bound": "mfma", "kernel": "gemm_i8_p3_kernel (fprop of the fake-quant linears on integer codes)",
+                                    "achieved": i8["tflops"], "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s",
+                                    "frac": i8["tflops"] / MFMA_I8_PEAK_TOPS, "avg_launch_ms": i8["avg_launch_ms"],
+                                    "launches_per_step": i8["launches_per_step"], "ms_per_step": i8["ms_per_step"],
+                                    "top_per_step": i8["tflop_per_step"]}
+        if roof["hbm"]:
+            top = roof["hbm"][0]
+            # the quantiser reductions are the HBM-class kernels of the step: the one with the most time per step leads
+            out["roofline_hbm"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["achieved_gbs"], "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": top["frac"], "avg_launch_us": top["avg_launch_us"],
+                                   "launches_per_step": top["launches_per_step"],
+                                   "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
+                                   "all_quantiser_kernels": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in h.items()}
+                                                             for h in roof["hbm"]]}
         if e2e is not None:
             out["end_to_end"] = e2e
         if world == 1 and not a.no_cpu_baseline:

@@ -359,11 +359,14 @@ def int_fprop_on():
     return os.environ.get("OQ_INT_FPROP", "1") != "0"
 
 
-def int_pre_dtype(act_dtype):
-    """dtype of a projection output that feeds a fused producer -> quantiser kernel (q | k | v -> RoPE -> head quantiser,
-    gate | up -> silu * up -> down_proj input quantiser) on the integer path: float32 by default, so that the exact GEMM
-    result is not rounded to bf16 in front of the next 4-bit rounding decision.  OQ_INT_PRE_F32=0: the activation dtype."""
-    return torch.float32 if os.environ.get("OQ_INT_PRE_F32", "1") != "0" else act_dtype
+def int_pre_dtype(act_dtype, site="qkv"):
+    """dtype of a projection output that feeds a fused producer -> quantiser kernel (site "qkv": q | k | v -> RoPE -> head
+    quantisers; site "mlp": gate | up -> silu * up -> down_proj input quantiser) on the integer path: float32 by default, so
+    that the exact GEMM result is not rounded to bf16 in front of the next 4-bit rounding decision.
+    OQ_INT_PRE_F32=0 / OQ_INT_PRE_F32_QKV=0 / OQ_INT_PRE_F32_MLP=0: the activation dtype (A/B switches)."""
+    dflt = {"qkv": "1", "mlp": "0"}[site]
+    on = os.environ.get("OQ_INT_PRE_F32", "1") != "0" and os.environ.get("OQ_INT_PRE_F32_" + site.upper(), dflt) != "0"
+    return torch.float32 if on else act_dtype
 
 
 def int_codes_supported(cols, seg, nbits, let):
@@ -1049,7 +1052,7 @@ class StackedGateUpFn(torch.autograd.Function):
         if wint is not None and (tuple(xint.codes.shape) != (rows, K) or tuple(wint.codes.shape) != (2 * I, K)):
             wint = None
         # integer path: the exact projection result stays fp32 when a quantiser reads it next (silu * up -> down_proj input)
-        pre_dtype = int_pre_dtype(x2.dtype) if (wint is not None and nbits) else x2.dtype
+        pre_dtype = int_pre_dtype(x2.dtype, "mlp") if (wint is not None and nbits) else x2.dtype
         pre = torch.empty((rows, 2 * I), dtype=pre_dtype, device=x2.device)
         es = pre.element_size()
         if wint is not None:

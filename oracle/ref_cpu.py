@@ -192,6 +192,23 @@ class _FusedAttnModel(torch.autograd.Function):
         return dq, dk, dv, None, None, None
 
 
+class _IntFpropLinear(torch.autograd.Function):
+    """Storage model of a Linear on the product path's INTEGER fprop (oq_gemm_i8): the forward product is exact -- the two
+    operands are contracted as integer codes, never rounded -- while dgrad / wgrad run on the operands as they are stored
+    for the bf16 MFMA (rounded to `dtype`).  Arithmetic fp32; the mathematics is quantize/int_linear.py:62."""
+
+    @staticmethod
+    def forward(ctx, x, w, dtype):
+        ctx.save_for_backward(x.to(dtype).to(x.dtype), w.to(dtype).to(w.dtype))
+        return F.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2, x2 = g.reshape(-1, g.shape[-1]), x.reshape(-1, x.shape[-1])
+        return (g2 @ w).view_as(x), g2.t() @ x2, None
+
+
 def _rounder(dtype):
     """None -> identity (the reference's pure-fp32 CPU arithmetic, the pinned mode)."""
     if dtype is None:
@@ -364,12 +381,14 @@ class Block:
         self.qparams[name] = (sc, zp)
         return y
 
-    def temporaries(self, store_dtype=None):
+    def temporaries(self, store_dtype=None, int_fprop=False):
         """Returns dict of temp tensors: '<linear>.weight', '<linear>.bias', '<ln>.weight', '<ln>.bias'.
         store_dtype (precision-mode emulation only): the fake-quantised weights are rounded to that dtype, as the
-        product path stores them for its bf16 MFMA GEMMs; biases and norm parameters stay fp32 there too."""
+        product path stores them for its bf16 MFMA GEMMs; biases and norm parameters stay fp32 there too.
+        int_fprop (precision-mode emulation only): the weights stay unrounded here -- forward(int_fprop=True) contracts
+        them exactly and rounds them for the backward products only (_IntFpropLinear)."""
         nm, P, W = self.names, self.params, self.w
-        rw = _rounder(store_dtype)
+        rw = _rounder(None if int_fprop else store_dtype)
         t = {}
         if self.spec.let:
             with torch.no_grad():
@@ -421,27 +440,43 @@ class Block:
             return (w * xh + b).to(x.dtype) if b is not None else (w * xh).to(x.dtype)
         return F.layer_norm(x, (self.H,), w, b, eps=self.eps)
 
-    def _lin(self, x, name, t, act_quant, rnd=None, residual=None, round_out=True):
+    def _lin(self, x, name, t, act_quant, rnd=None, residual=None, round_out=True, int_dtype=None):
         w = t[name + ".weight"] if t else self.w[name + ".weight"]
         b = t[name + ".bias"] if t else self.w.get(name + ".bias")
         xin = self._aq(x, act_quant)
-        if rnd is not None and act_quant and self.spec.abits < 16:
-            xin = rnd(xin)                                  # the quantised activation is stored before the GEMM
-        y = F.linear(xin, w, b)
+        if int_dtype is not None and act_quant and self.spec.abits < 16:
+            # integer fprop: exact forward product of the two quantised operands, bf16 operands in the backward products
+            y = _IntFpropLinear.apply(xin, w, int_dtype)
+            if b is not None:
+                y = y + b
+        else:
+            if rnd is not None and act_quant and self.spec.abits < 16:
+                xin = rnd(xin)                              # the quantised activation is stored before the GEMM
+            y = F.linear(xin, w, b)
         if residual is not None:
             y = residual + y                                # (the product path adds the residual in the GEMM's store)
-        return rnd(y) if (rnd is not None and round_out) else y
+        if rnd is not None and round_out:
+            return rnd(y)
+        if int_dtype is not None:
+            return _GradRoundSTE.apply(y, int_dtype)        # value kept in fp32 for a fused quantiser, its gradient is stored in bf16
+        return y
 
-    def forward(self, x, mask=None, position_ids=None, temps=None, act_quant=True, act_dtype=None):
+    def forward(self, x, mask=None, position_ids=None, temps=None, act_quant=True, act_dtype=None, int_fprop=False):
         """x [bs,T,H].  temps=None -> raw (or folded) weights; act_quant toggles every activation quantizer.
         act_dtype (precision-mode emulation only, default None = the reference's fp32 arithmetic): every activation the
         product path materialises between two kernels is rounded to that dtype (value and gradient), arithmetic stays
-        fp32 -- the CPU model of the bf16 production mode."""
+        fp32 -- the CPU model of the bf16 production mode.
+        int_fprop (with act_dtype, weight-activation configurations on grids of at most 8 bits without weight groups): the
+        product path's integer fprop -- every Linear's forward product is exact (_IntFpropLinear; `temps` must come from
+        temporaries(int_fprop=True)), and the q | k | v projection output, which feeds the fused RoPE -> head quantisers, stays
+        fp32 (head_dim 128)."""
         nm = self.names
         bs, T, H = x.shape
         R_ = _rounder(act_dtype)
         rnd = R_ if act_dtype is not None else None
         aq4 = act_quant and self.spec.abits < 16
+        idt = act_dtype if (int_fprop and act_dtype is not None and aq4 and self.spec.abits <= 8 and self.spec.wbits <= 8
+                            and not self.spec.group_size) else None
         # (with activation quantisation on, the product path fuses norm -> input quantiser: the norm output is not stored)
         fused_nq = act_dtype is not None and aq4 and 512 <= H <= 8192 and H % 8 == 0
         h = self._norm(x, nm["ln1"], temps)
@@ -451,9 +486,10 @@ class Block:
             # with head-wise activation quantisation on (head_dim 128), the product path rotates and quantises the stored
             # projection output in one kernel: the rotated tensor is never stored
             keep = act_dtype is not None and aq4 and self.hd == 128
-            q = self._lin(h, nm["q"], temps, act_quant, rnd).view(bs, T, self.nh, self.hd).transpose(1, 2)
-            k = self._lin(h, nm["k"], temps, act_quant, rnd).view(bs, T, self.nkv, self.hd).transpose(1, 2)
-            v = self._lin(h, nm["v"], temps, act_quant, rnd).view(bs, T, self.nkv, self.hd).transpose(1, 2)
+            pre_f32 = idt is not None and keep          # integer path: the projection output reaches the fused quantiser in fp32
+            q = self._lin(h, nm["q"], temps, act_quant, rnd, round_out=not pre_f32, int_dtype=idt).view(bs, T, self.nh, self.hd).transpose(1, 2)
+            k = self._lin(h, nm["k"], temps, act_quant, rnd, round_out=not pre_f32, int_dtype=idt).view(bs, T, self.nkv, self.hd).transpose(1, 2)
+            v = self._lin(h, nm["v"], temps, act_quant, rnd, round_out=not pre_f32, int_dtype=idt).view(bs, T, self.nkv, self.hd).transpose(1, 2)
             cos = self.cos[:T][position_ids].unsqueeze(1)
             sin = self.sin[:T][position_ids].unsqueeze(1)
             q = q * cos + _rot_half(q) * sin
@@ -482,17 +518,18 @@ class Block:
                     att = torch.max(att, torch.tensor(torch.finfo(att.dtype).min))
                 att = F.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
                 o = R_(torch.matmul(R_(att), v).transpose(1, 2).reshape(bs, T, H))
-            h = self._lin(o, nm["o"], temps, act_quant, rnd, residual=x)
+            h = self._lin(o, nm["o"], temps, act_quant, rnd, residual=x, int_dtype=idt)
             h2 = self._norm(h, nm["ln2"], temps)
             if not fused_nq:
                 h2 = R_(h2)
-            gate = self._lin(h2, "mlp.gate_proj", temps, act_quant, rnd)
-            up = self._lin(h2, "mlp.up_proj", temps, act_quant, rnd)
+            # (gate | up are stored in bf16 on the integer path too: keeping them fp32 was measured to change nothing)
+            gate = self._lin(h2, "mlp.gate_proj", temps, act_quant, rnd, int_dtype=idt)
+            up = self._lin(h2, "mlp.up_proj", temps, act_quant, rnd, int_dtype=idt)
             act = F.silu(gate) * up
             if not aq4:
                 act = R_(act)          # stored before the GEMM; with activation quantisation on, the product path fuses
                 #                        silu*up into the down_proj input quantiser and the product stays fp32
-            return self._lin(act, "mlp.down_proj", temps, act_quant, rnd, residual=h)
+            return self._lin(act, "mlp.down_proj", temps, act_quant, rnd, residual=h, int_dtype=idt)
         # ---- OPT: q/k/v are quantised per token over the full hidden dim before the head split
         scaling = self.hd ** -0.5
         q = self._aq(R_(self._lin(h, nm["q"], temps, act_quant, rnd) * scaling), act_quant)

@@ -67,7 +67,9 @@ def test_production_step_vs_oracle(name):
     torch.set_num_threads(max(cores, 1))
     layer = S.make_layer(cfg, seed=0, device="cpu")
     weights = {n: p.detach().float() for n, p in layer.named_parameters()}
-    x = S.make_calib_inputs(1, T, H, dtype=torch.float32)
+    # the calibration bank is DATA stored in 16 bits on both sides (reference: fp16 `inps`, quantize/omniquant.py:77-79; here
+    # bf16): every run below -- fp32 oracle, storage model, HIP -- sees the same bf16-representable sample
+    x = S.make_calib_inputs(1, T, H, dtype=torch.float32).to(torch.bfloat16).float()
     mask, pos = S.causal_mask(T), torch.arange(T)[None]
     sc, sh = S.synth_act_stats(cfg, 1)
     # ---- oracle: teacher target + one train_step ---------------------------------------------------------------------
@@ -88,14 +90,16 @@ def test_production_step_vs_oracle(name):
     del temps, out
     t_cpu = time.time() - t0
     # ---- oracle again in the bf16 storage model (weight-activation configurations only) ------------------------------
-    emu_grad, loss_e = None, None
+    emu_grad, loss_e, use_int = None, None, False
     if abits < 16:
         blk2 = R.Block("llama", cd, weights, R.QuantSpec(wbits, abits, group, True, let), max_pos=T)
         if let:
             blk2.register_let(sc, sh, alpha, 0, "model.layers")
         bf = torch.bfloat16
-        temps2 = blk2.temporaries(store_dtype=bf)
-        out2 = blk2.forward(x.to(bf).float(), mask, pos, temps=temps2, act_quant=True, act_dtype=bf)
+        from omniquant_amd import ops as _ops
+        use_int = _ops.int_fprop_on() and group is None and abits <= 8 and wbits <= 8       # the product's integer fprop (oq_gemm_i8)
+        temps2 = blk2.temporaries(store_dtype=bf, int_fprop=use_int)
+        out2 = blk2.forward(x.to(bf).float(), mask, pos, temps=temps2, act_quant=True, act_dtype=bf, int_fprop=use_int)
         loss_e = torch.nn.functional.mse_loss(tgt.to(bf).float(), out2)
         loss_e.backward()
         emu_grad = {n: p.grad.detach().clone() for n, p in blk2.params.items()}
@@ -142,7 +146,7 @@ def test_production_step_vs_oracle(name):
         # but not its online-softmax tile order, which moves that noise floor.  Measured 0.978 .. 0.989 / 0.15 .. 0.21.
         if emu_grad is not None and any(t in n for t in ("q_proj", "k_proj", "qkt_smooth")):
             ok = cos >= 0.97 and l2 <= 0.25
-        elif emu_grad is not None and "v_proj" in n:
+        elif emu_grad is not None and ("v_proj" in n or "out_smooth" in n):      # behind P @ V as well
             ok = cos >= 0.98 and l2 <= 0.2
         elif emu_grad is not None:
             ok = cos >= 0.995 and l2 <= 0.1
@@ -150,6 +154,15 @@ def test_production_step_vs_oracle(name):
             ok = cos >= 0.99 and l2 <= 5e-2
         if not ok:
             fails.append((n, round(cos, 5), round(l2, 4)))
+        # Regression floor against the PLAIN fp32 oracle step (same bf16-representable inputs), whatever the storage model says:
+        # measured this round with the integer fprop -- 7B: 0.923 .. 0.938 on the attention-score path, >= 0.993 elsewhere; 13B:
+        # 0.899 .. 0.906, 0.93 (v_proj) / 0.968 (out_smooth_scale), >= 0.984 elsewhere.  What is left on the score path is the
+        # 16-bit attention itself (bf16 q / k / v operands, P, dS: tests/diag/rounding_points.py), as in the reference's fp16 run.
+        if emu_grad is not None:
+            c32 = rep["grads"][n]["cos"]
+            floor = 0.86 if any(t in n for t in ("q_proj", "k_proj", "qkt_smooth")) else (0.90 if ("v_proj" in n or "out_smooth" in n) else 0.975)
+            if use_int and c32 < floor:
+                fails.append((n, "vs plain fp32", round(c32, 5), "floor", floor))
     mods = {n: m for n, m in q.named_modules() if isinstance(m, QuantLinear)}
     for n, ref in ref_tw.items():
         got = mods[n].temp_weight.detach().float().cpu().numpy().astype(np.float64)
