@@ -56,7 +56,8 @@ def case(name, rows, cols, let, lwc, act, nbytes_f, nbytes_b):
 
     def fwd():
         C.call("oq_fakequant_fwd", C.ptr(W), C.dt(W), rows, cols, cols, 4, 0, P(cm), P(rd), None, P(sh), P(up), P(low),
-               C.ptr(y), 2, P(sc), P(zp), P(xmn), P(xmx), P(wsh if let else None), CODES, CSUM, st)
+               C.ptr(y), 2, P(sc), P(zp), P(xmn), P(xmx), P(wsh if let else None),
+               CODES if os.environ.get("OQ_ROWQ") != "0" else None, CSUM if os.environ.get("OQ_ROWQ") != "0" else None, st)
 
     def bwd():
         ws_n = C.size_call("oq_fakequant_bwd_workspace", rows, cols)
