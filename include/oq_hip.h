@@ -244,6 +244,10 @@ int oq_silu_mul_quant_fwd(const void* gate, const void* up, int dtype, int64_t r
                           int y_dtype, float* scale, float* zp, float* xmin, float* xmax, void* codes, float* csum, void* stream);
 int oq_silu_mul_quant_bwd(const void* gate, const void* up, const void* g, int dtype, int g_dtype, int64_t rows, int64_t cols,
                           int64_t ld, int nbits, const float* xmin, const float* xmax, void* ggate, void* gup, void* stream);
+/* Grouped-query attention, backward of repeat_kv (models/int_llama_layer.py:136-141): y[g][d] = sum_r x[g][r][d] for
+ * x [groups, rep, hd] -> y [groups, hd] (groups = rows * kv heads; fp32 sum in head order, one rounding), for one or two
+ * tensors (dK and dV; x1 / y1 may be NULL) in one launch.  hd multiple of 8, dtype OQ_BF16 or OQ_F32. */
+int oq_group_sum(const void* x0, void* y0, const void* x1, void* y1, int dtype, int64_t groups, int rep, int64_t hd, void* stream);
 int oq_relu_fwd(const void* x, void* y, int dtype, int64_t n, void* stream);
 int oq_relu_bwd(const void* x, const void* gy, void* gx, int dtype, int64_t n, void* stream);
 int oq_softmax_fwd(const void* s, void* p, int dtype, int64_t rows, int64_t cols, float alpha, const float* mask,
@@ -313,10 +317,14 @@ int oq_adamw(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_
  * when the gradients are finite), then AdamW (as oq_adamw, reading the advanced counter) which also applies truncate_number
  * (models/transformation.py:5-20, threshold truncate_thr) to the first n_truncate parameters -- the LET scales, what the
  * reference does at the top of the NEXT step (models/int_llama_layer.py:281-284) -- and clears g when zero_grads != 0
- * (the optimizer.zero_grad() of quantize/omniquant.py:225, moved behind the update).  workspace: 512 floats. */
+ * (the optimizer.zero_grad() of quantize/omniquant.py:225, moved behind the update).  workspace: 512 floats.
+ * step_log (optional, 1 + 2 * step_log_len floats): the per-step record the reference reads back with loss.item() /
+ * norm.cpu() every step (quantize/omniquant.py:223-231) kept on the device instead -- step_log[0] counts the steps logged
+ * since the host last zeroed it, entry k is (loss[0], gradient norm) of step k (written while k < step_log_len; `loss` may be
+ * NULL).  The host reads the log once per epoch. */
 int oq_adamw_step(float* p, float* g, float* m, float* v, int64_t n, int64_t n_let, int64_t n_truncate, float truncate_thr,
                   int zero_grads, float lr_let, float lr_lwc, float beta1, float beta2, float eps, float wd, float* step_ptr,
-                  float* norm_out, float* workspace, void* stream);
+                  float* norm_out, float* workspace, const float* loss, float* step_log, int64_t step_log_len, void* stream);
 int oq_truncate(float* x, int64_t n, float thr, void* stream);
 /* dst[e][i] = sum_k src[e*OQ_SUM_MAX_SRC + k][i], k < nsrc[e], i < n[e], for e < entries, in one launch and in a fixed
  * order.  Gathers the partial gradients several backward kernels produce for one shared LET parameter into the

@@ -43,6 +43,7 @@ SIGNATURES = {
     "oq_qkv_rope_quant_bwd": [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "oq_silu_mul_quant_fwd": [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "oq_silu_mul_quant_bwd": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
+    "oq_group_sum": [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _i64, _vp],
     "oq_relu_fwd": [_vp, _vp, _i32, _i64, _vp],
     "oq_relu_bwd": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_softmax_fwd": [_vp, _vp, _i32, _i64, _i64, _f32, _vp, _i64, _i32, _vp],
@@ -55,7 +56,8 @@ SIGNATURES = {
     "oq_copy_samples": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_gradnorm": [_vp, _i64, _vp, _vp, _vp],
     "oq_adamw": [_vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp],
-    "oq_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp, _vp],
+    "oq_adamw_step": [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp, _vp,
+                      _vp, _vp, _i64, _vp],
     "oq_truncate": [_vp, _i64, _f32, _vp],
     "oq_act_stats": [_vp, _i32, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _vp],
     "oq_pack_weights": [_vp, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],

@@ -126,6 +126,8 @@ class StepRunner:
         return self.qlayer(self.x, attention_mask=self.mask)[0]
 
     def _step(self):
+        from .ops import WeightQuantBatch
+        WeightQuantBatch.drop_stale()       # nothing of a previous (possibly failed) step may be launched by this one
         self.qlayer.smooth_and_quant_temporary()
         out = self._forward()
         g = torch.empty_like(out)
@@ -148,6 +150,8 @@ class StepRunner:
                 self._step()
             for t, c in zip((opt.flat, opt.exp_avg, opt.exp_avg_sq, opt.step_count), snap):
                 t.copy_(c)
+            if opt.step_log is not None:
+                opt.step_log[:1].zero_()          # the warm-up steps are not part of the record
             # the captured step starts from scales the fused update keeps truncated: do it once for the restored values
             opt.truncate_scales(force=True)
             self.qlayer.clear_temp_variable()     # drop the warm-up autograd graph
@@ -230,15 +234,27 @@ def calibrate_block(qlayer, args, family, layer_idx, quant_inps, fp_inps, fp_inp
                             position_ids, (bs,) + tuple(quant_inps.shape[1:]), compute_dtype, args.aug_loss, is_llama,
                             use_graph)
         nsteps = nsamples // bs
-        loss_buf = torch.zeros(nsteps, dtype=torch.float32, device=dev)
-        norm_buf = torch.zeros(nsteps, dtype=torch.float32, device=dev)
+        # loss and gradient norm of every step are appended to a device log by the step's own optimiser launch (captured in
+        # the graph): the loop issues nothing per step besides the sample copy and the replay
+        on_device_log = opt.fused            # (OQ_FUSED_OPT=0, the A/B path with separate launches, copies per step instead)
+        if on_device_log:
+            opt.attach_step_log(runner.loss, nsteps)
+        else:
+            loss_buf = torch.zeros(nsteps, dtype=torch.float32, device=dev)
+            norm_buf = torch.zeros(nsteps, dtype=torch.float32, device=dev)
         for epoch in range(args.epochs):
             for j in range(nsteps):
                 i0 = j * bs
                 runner.run(quant_inps[i0:i0 + bs], fp_inps[i0:i0 + bs], fp_inps_2[i0:i0 + bs] if args.aug_loss else None)
-                loss_buf[j:j + 1].copy_(runner.loss)
-                norm_buf[j:j + 1].copy_(opt.norm[0:1])
-            ep_loss, ep_norm = loss_buf.tolist(), norm_buf.tolist()      # ONE sync per epoch
+                if not on_device_log:
+                    loss_buf[j:j + 1].copy_(runner.loss)
+                    norm_buf[j:j + 1].copy_(opt.norm[0:1])
+            if on_device_log:
+                ep_loss, ep_norm = opt.read_step_log()                   # ONE sync per epoch
+                if len(ep_loss) != nsteps:
+                    raise C.OQError(f"layer {layer_idx} epoch {epoch}: the step log holds {len(ep_loss)} of {nsteps} steps")
+            else:
+                ep_loss, ep_norm = loss_buf.tolist(), norm_buf.tolist()
             losses += ep_loss
             norms += ep_norm
             if not all(math.isfinite(v) for v in ep_loss):

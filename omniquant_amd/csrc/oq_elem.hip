@@ -438,6 +438,51 @@ extern "C" int oq_scale(const void* a, float s, void* y, int dtype, int64_t n, v
     EW_FWD("oq_scale", 3, a, a, s);
 }
 
+// ---- grouped-query attention: dK / dV of a key-value head = sum over the `rep` query heads that share it ------------------
+// (repeat_kv's backward, models/int_llama_layer.py:136-141).  x [rows, nkv, rep, hd] -> y [rows, nkv, hd], fp32 sum in head
+// order, one rounding; up to two tensors (dK and dV) in one launch.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) group_sum_kernel(const T* x0, T* y0, const T* x1, T* y1, int64_t nvec_out, int rep, int hd8) {
+    const T* x = blockIdx.y ? x1 : x0;
+    T* y = blockIdx.y ? y1 : y0;
+    for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec_out; v += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = v / hd8, c = v - g * hd8;            // g = (row, kv head), c = 8-element chunk inside the head
+        float acc[8];
+        Vec8<T>::load(x + ((g * rep) * hd8 + c) * 8, acc);
+        for (int r = 1; r < rep; ++r) {
+            float t[8];
+            Vec8<T>::load(x + ((g * rep + r) * hd8 + c) * 8, t);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += t[i];
+        }
+        Vec8<T>::store(y + v * 8, acc);
+    }
+}
+}  // namespace
+
+extern "C" int oq_group_sum(const void* x0, void* y0, const void* x1, void* y1, int dtype, int64_t groups, int rep, int64_t hd,
+                            void* stream) {
+    OQ_CHECK_ARG(x0 && y0 && ((x1 == nullptr) == (y1 == nullptr)), "oq_group_sum: null pointer");
+    OQ_CHECK_ARG(groups > 0 && rep >= 1 && hd > 0 && hd % 8 == 0, "oq_group_sum: groups %lld rep %d hd %lld (hd multiple of 8)",
+                 (long long)groups, rep, (long long)hd);
+    OQ_CHECK_ARG(oq_aligned16(x0) && oq_aligned16(y0) && oq_aligned16(x1) && oq_aligned16(y1), "oq_group_sum: 16-byte alignment");
+    const int hd8 = (int)(hd / 8);
+    const int64_t nvec = groups * hd8;
+    const dim3 grid((unsigned)((nvec + 255) / 256 < 4096 ? (nvec + 255) / 256 : 4096), x1 ? 2 : 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == OQ_BF16)
+        hipLaunchKernelGGL((group_sum_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x0, (bf16_t*)y0, (const bf16_t*)x1, (bf16_t*)y1, nvec, rep, hd8);
+    else if (dtype == OQ_F32)
+        hipLaunchKernelGGL((group_sum_kernel<float>), grid, dim3(256), 0, st, (const float*)x0, (float*)y0, (const float*)x1, (float*)y1, nvec, rep, hd8);
+    else {
+        oq_set_error("oq_group_sum: dtype %d unsupported", dtype);
+        return OQ_E_UNSUPPORTED;
+    }
+    OQ_CHECK_LAUNCH("oq_group_sum");
+    return OQ_OK;
+}
+
 // ---- the step's input sample(s) -> the static buffers a replayed hipGraph reads: up to three 16-byte-granular copies in
 // ONE launch (quantize/omniquant.py:216-219 indexes the banks in place; a captured graph needs fixed addresses)
 namespace {

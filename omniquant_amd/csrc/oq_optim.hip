@@ -66,7 +66,8 @@ __global__ void __launch_bounds__(256) adamw_kernel(float* p, const float* g, fl
 // oq_gradnorm + oq_adamw + oq_truncate + a fill.  (Finishing the reduction in the first launch through a "last
 // workgroup" ticket was measured and dropped: the agent-scope fences it needs write back and invalidate the L2 of every
 // XCD -- the step became 20 % slower.)
-__global__ void __launch_bounds__(64) gradnorm_final_step_kernel(const float* ws, int nblocks, float* out, float* step_ptr) {
+__global__ void __launch_bounds__(64) gradnorm_final_step_kernel(const float* ws, int nblocks, float* out, float* step_ptr,
+                                                                 const float* loss, float* log, int64_t log_len) {
     float ss = 0.f, bad = 0.f;
     for (int i = threadIdx.x; i < nblocks; i += 64) { ss += ws[2 * i]; bad = fmaxf(bad, ws[2 * i + 1]); }
     ss = wave_sum(ss);
@@ -76,6 +77,17 @@ __global__ void __launch_bounds__(64) gradnorm_final_step_kernel(const float* ws
         out[0] = sqrtf(ss);
         out[1] = finite ? 1.f : 0.f;
         if (finite) step_ptr[0] += 1.f;       // the AdamW launch behind this one reads the advanced counter
+        if (log) {
+            // step log: log[0] = number of steps logged since the host last reset it, then (loss, grad norm) pairs -- what the
+            // reference fetches with loss.item() every step (quantize/omniquant.py:223-231) stays on the device until the
+            // epoch's single read-back
+            const int64_t cur = (int64_t)log[0];
+            if (cur < log_len) {
+                log[1 + 2 * cur] = loss ? loss[0] : 0.f;
+                log[2 + 2 * cur] = out[0];
+            }
+            log[0] = (float)(cur + 1);
+        }
     }
 }
 
@@ -149,14 +161,17 @@ extern "C" int oq_adamw(float* p, const float* g, float* m, float* v, int64_t n,
 
 extern "C" int oq_adamw_step(float* p, float* g, float* m, float* v, int64_t n, int64_t n_let, int64_t n_truncate,
                              float truncate_thr, int zero_grads, float lr_let, float lr_lwc, float beta1, float beta2, float eps,
-                             float wd, float* step_ptr, float* norm_out, float* workspace, void* stream) {
+                             float wd, float* step_ptr, float* norm_out, float* workspace, const float* loss, float* step_log,
+                             int64_t step_log_len, void* stream) {
     OQ_CHECK_ARG(p && g && m && v && step_ptr && norm_out && workspace && n > 0 && n_let >= 0 && n_let <= n &&
                  n_truncate >= 0 && n_truncate <= n, "oq_adamw_step: bad args (workspace needs %d floats)", 2 * GN_BLOCKS);
+    OQ_CHECK_ARG(!step_log || step_log_len > 0, "oq_adamw_step: step log of %lld entries", (long long)step_log_len);
     hipStream_t st = (hipStream_t)stream;
     int64_t nb = (n + 255) / 256;
     const int64_t gb = nb > GN_BLOCKS ? GN_BLOCKS : nb;
     hipLaunchKernelGGL(gradnorm_partial_kernel, dim3(gb), dim3(256), 0, st, (const float*)g, n, workspace);
-    hipLaunchKernelGGL(gradnorm_final_step_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, (int)gb, norm_out, step_ptr);
+    hipLaunchKernelGGL(gradnorm_final_step_kernel, dim3(1), dim3(64), 0, st, (const float*)workspace, (int)gb, norm_out, step_ptr,
+                       loss, step_log, step_log_len);
     nb = nb > 2048 ? 2048 : nb;
     hipLaunchKernelGGL(adamw_fused_kernel, dim3(nb), dim3(256), 0, st, p, g, m, v, n, n_let, n_truncate, truncate_thr, zero_grads,
                        lr_let, lr_lwc, beta1, beta2, eps, wd, (const float*)step_ptr, (const float*)norm_out);

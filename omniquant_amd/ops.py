@@ -77,6 +77,10 @@ class WeightQuantBatch:
     def add_backward(self, args, keep):
         if not self.bwd:
             WeightQuantBatch.pending.append(self)
+            # the deferred launch goes to the stream the siblings' buffers were produced on (with OQ_WEIGHT_STREAM=1 that is the
+            # block's side stream, not the stream of whoever flushes): the caching allocator then cannot hand `keep`'s buffers,
+            # released right after the launch, to work that is ordered before it
+            self.stream = torch.cuda.current_stream()
             # a sibling that needs no gradient never arrives: whatever is still queued goes out when this backward pass ends
             torch.autograd.Variable._execution_engine.queue_callback(WeightQuantBatch.flush_pending)
         self.bwd.append(args)
@@ -91,13 +95,28 @@ class WeightQuantBatch:
             arr = (C.FakeQuantBwdArgs * len(self.bwd))()
             for i, a in enumerate(self.bwd):
                 arr[i] = C.FakeQuantBwdArgs(*a)
-            C.call("oq_fakequant_bwd_multi", ctypes.addressof(arr), len(self.bwd), C.stream())
+            st = getattr(self, "stream", None) or torch.cuda.current_stream()
+            cur = torch.cuda.current_stream()
+            if st != cur:
+                st.wait_stream(cur)           # the last sibling's gradient may have been produced on the flusher's stream
+            C.call("oq_fakequant_bwd_multi", ctypes.addressof(arr), len(self.bwd), st.cuda_stream)
+            if st != cur:
+                cur.wait_stream(st)           # the outputs feed the optimiser arena, read on the flusher's stream
         self.bwd, self.keep = [], []
 
     @staticmethod
     def flush_pending():
         for b in list(WeightQuantBatch.pending):
             b.flush_backward()
+
+    @staticmethod
+    def drop_stale():
+        """Start of a new step: a backward pass that raised may have left batches queued whose buffers are gone -- forget
+        them instead of launching them with the next flush."""
+        for b in WeightQuantBatch.pending:
+            b.bwd, b.keep = [], []
+        WeightQuantBatch.pending = []
+        WeightQuantBatch.active = None
 
 
 class FakeQuantFn(torch.autograd.Function):
@@ -387,13 +406,17 @@ def stacked_int(ints):
     return IntCodes(codes, vecs[0], vecs[1], vecs[2], ints[0].nbits)
 
 
-def gemm_i8(a, b, c, bias=None, addend=None):
+def gemm_i8(a, b, c, bias=None, addend=None, c_off=0):
     """c[M, N] = dequant(a)[M, K] @ dequant(b)[N, K]^T + bias (+ addend), contracted exactly on the int8 MFMA (oq_gemm_i8).
-    a, b: IntCodes; c: preallocated [M, N] float32 / bfloat16 GPU tensor."""
+    a, b: IntCodes; c: preallocated float32 / bfloat16 GPU tensor -- [M, N], or [M, ldc] with the result written to the
+    column block [c_off, c_off + N) (sibling projections sharing one output buffer)."""
     M, K = a.codes.shape
     N = b.codes.shape[0]
-    if b.codes.shape[1] != K or tuple(c.shape) != (M, N):
-        raise C.OQError(f"gemm_i8: shapes a {tuple(a.codes.shape)} b {tuple(b.codes.shape)} c {tuple(c.shape)}")
+    ldc = c.shape[-1]
+    if b.codes.shape[1] != K or c.dim() != 2 or c.shape[0] != M or c_off < 0 or c_off + N > ldc or not c.is_contiguous():
+        raise C.OQError(f"gemm_i8: shapes a {tuple(a.codes.shape)} b {tuple(b.codes.shape)} c {tuple(c.shape)} offset {c_off}")
+    if addend is not None and (ldc != N or c_off):
+        raise C.OQError("gemm_i8: addend only with a dense [M, N] output")
     for t in (a.codes, b.codes):
         if t.dtype != torch.int8 or not t.is_cuda or not t.is_contiguous():
             raise C.OQError("gemm_i8: codes must be contiguous int8 GPU tensors; there is no CPU fallback")
@@ -402,9 +425,9 @@ def gemm_i8(a, b, c, bias=None, addend=None):
             raise C.OQError("gemm_i8: per-row vectors must be float32 with one entry per row")
     if addend is not None and (addend.dtype != c.dtype or tuple(addend.shape) != (M, N) or not addend.is_contiguous()):
         raise C.OQError("gemm_i8: addend must be a contiguous tensor of the output's dtype and shape")
-    C.call("oq_gemm_i8", C.ptr(a.codes), C.ptr(b.codes), C.ptr(c), C.fptr(bias), C.ptr(addend),
+    C.call("oq_gemm_i8", C.ptr(a.codes), C.ptr(b.codes), c.data_ptr() + c_off * c.element_size(), C.fptr(bias), C.ptr(addend),
            C.fptr(a.scale), C.fptr(a.zp), C.fptr(a.csum), C.fptr(b.scale), C.fptr(b.zp), C.fptr(b.csum),
-           M, N, K, K, K, N, a.nbits, b.nbits, C.dt(c), C.stream())
+           M, N, K, K, K, ldc, a.nbits, b.nbits, C.dt(c), C.stream())
 
 
 class SiblingGrads:
@@ -588,10 +611,17 @@ class QKVRopeQuantFn(torch.autograd.Function):
         wint = stacked_int(list(wints)) if (ctx.stacked and xint is not None and wints is not None) else None
         if wint is not None and (tuple(xint.codes.shape) != (rows, K) or tuple(wint.codes.shape) != (Ntot, K)):
             wint = None
-        pre = torch.empty((rows, Ntot), dtype=int_pre_dtype(x2.dtype) if wint is not None else x2.dtype, device=x2.device)
+        each_int = (wint is None and xint is not None and wints is not None and tuple(xint.codes.shape) == (rows, K)
+                    and all(tuple(wi.codes.shape) == (N, K) for wi, N in zip(wints, Ns)))
+        pre = torch.empty((rows, Ntot), dtype=int_pre_dtype(x2.dtype) if (wint is not None or each_int) else x2.dtype,
+                          device=x2.device)
         if wint is not None:
             # integer-exact projections (oq_gemm_i8); the result reaches RoPE and the head quantisers in fp32
             gemm_i8(xint, wint, pre, bias=ball)
+        elif each_int:
+            # the same per matrix (weights not stacked): identical integer accumulators, identical results
+            for wi, b, off in zip(wints, bs_, offs):
+                gemm_i8(xint, wi, pre, bias=_f32(b), c_off=off)
         elif ctx.stacked:
             # the three fake-quant weights are row blocks of one buffer: ONE GEMM with N = Nq + Nk + Nv
             gemm(x2, wall, pre, rows, Ntot, K, K, K, Ntot, True, True, bias=ball)
@@ -785,7 +815,7 @@ class AttnScoresFn(torch.autograd.Function):
             gemm(gs, q, gk_full, Tk, hd, T, Tk, nh * hd, nh * hd, False, False, batch_o=nh, batch_i=1,
                  sa=(T * Tk, 0), sb=(hd, 0), sc=(hd, 0),
                  a_off=b * nh * T * Tk, b_off=b * T * nh * hd, c_off=b * Tk * nh * hd, tri=3 if ctx.causal else 0)
-        gk = gk_full if rep == 1 else gk_full.view(bs, Tk, nkv, rep, hd).sum(dim=3)
+        gk = gk_full if rep == 1 else group_sum(gk_full, nkv, rep)[0]
         return gq, gk, None
 
 
@@ -827,7 +857,7 @@ class AttnPVFn(torch.autograd.Function):
             gemm(p, go, gv_full, Tk, hd, T, Tk, nh * hd, nh * hd, False, False, batch_o=nh, batch_i=1,
                  sa=(T * Tk, 0), sb=(hd, 0), sc=(hd, 0),
                  a_off=b * nh * T * Tk, b_off=b * T * nh * hd, c_off=b * Tk * nh * hd, tri=3 if ctx.causal else 0)
-        gv = gv_full if rep == 1 else gv_full.view(bs, Tk, nkv, rep, hd).sum(dim=3)
+        gv = gv_full if rep == 1 else group_sum(gv_full, nkv, rep)[0]
         return gp, gv, None
 
 
@@ -1285,9 +1315,28 @@ class FusedCausalAttnFn(torch.autograd.Function):
         if rep == 1:
             gk, gv = gk_full, gv_full
         else:
-            gk = gk_full.view(bs, T, nkv, rep, hd).sum(dim=3)
-            gv = gv_full.view(bs, T, nkv, rep, hd).sum(dim=3)
+            gk, gv = group_sum(gk_full, nkv, rep, gv_full)       # dK and dV of the shared heads: one launch of ours
         return gq, gk, gv, None
+
+
+def group_sum(x, nkv, rep, x2=None):
+    """Backward of repeat_kv for grouped-query attention: x [bs, T, nkv * rep, hd] (query-head order: head h belongs to
+    key-value head h // rep) -> [bs, T, nkv, hd], summed over the rep query heads of each group (oq_group_sum).  With x2 the
+    same for a second tensor in the same launch.  Returns (y, y2)."""
+    bs, T, nh, hd = x.shape
+    if nh != nkv * rep or (x2 is not None and (x2.shape != x.shape or x2.dtype != x.dtype)):
+        raise C.OQError(f"group_sum: shape {tuple(x.shape)} for nkv {nkv} rep {rep}")
+    if x.dtype not in (torch.bfloat16, torch.float32) or hd % 8 != 0 or not x.is_cuda:
+        y = x.view(bs, T, nkv, rep, hd).sum(dim=3)
+        return y, (None if x2 is None else x2.view(bs, T, nkv, rep, hd).sum(dim=3))
+    x = x.contiguous()
+    y = torch.empty((bs, T, nkv, hd), dtype=x.dtype, device=x.device)
+    y2 = None
+    if x2 is not None:
+        x2 = x2.contiguous()
+        y2 = torch.empty_like(y)
+    C.call("oq_group_sum", C.ptr(x), C.ptr(y), C.ptr(x2), C.ptr(y2), C.dt(x), bs * T * nkv, int(rep), hd, C.stream())
+    return y, y2
 
 
 class AddFn(torch.autograd.Function):

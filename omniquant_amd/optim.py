@@ -111,9 +111,30 @@ class BlockOptimizer:
         # OQ_FUSED_OPT=0 keeps the separate launches for A/B.
         self.fused = os.environ.get("OQ_FUSED_OPT", "1") != "0"
         self.truncate_thr = 1e-2
+        # on-device step log (oq_adamw_step): (loss, gradient norm) of every step since the last reset; set by attach_step_log
+        self.step_log = None
+        self._log_loss = None
         self.clear_grads_in_step = True   # False: .grad survives step() as with torch (tests that read the gradients)
         self._grads_clean = True          # the arena is all zeros (set by the fused step, cleared by anything that may write it)
         self._scales_truncated = False    # the scales are known to satisfy |s| >= thr (set by the fused step)
+
+    def attach_step_log(self, loss, n_steps):
+        """Have every fused step append (loss[0], gradient norm) to a device buffer instead of the host fetching them per step
+        (quantize/omniquant.py:223-231 does loss.item() each step).  `loss`: the 1-element float32 device tensor the step's
+        loss kernel writes.  Read with read_step_log() -- one sync per epoch -- which also rewinds the log."""
+        if loss.dtype != torch.float32 or loss.numel() != 1 or not loss.is_cuda:
+            raise C.OQError("attach_step_log: loss must be a 1-element float32 GPU tensor")
+        self._log_loss = loss
+        self.step_log = torch.zeros(1 + 2 * int(n_steps), dtype=torch.float32, device=self.flat.device)
+
+    def read_step_log(self):
+        """(losses, norms) of the steps logged since the last call; ONE device-to-host copy, then the log is rewound."""
+        if self.step_log is None:
+            return [], []
+        host = self.step_log.tolist()
+        n = min(int(host[0]), (len(host) - 1) // 2)
+        self.step_log[:1].zero_()
+        return host[1:1 + 2 * n:2], host[2:2 + 2 * n:2]
 
     def zero_grad(self, set_to_none=False, lazy=False):
         """lazy=True (the engine's own step loop): skip the launch when the fused step has just cleared the arena."""
@@ -147,7 +168,8 @@ class BlockOptimizer:
             C.call("oq_adamw_step", C.fptr(self.flat), C.fptr(self.grad), C.fptr(self.exp_avg), C.fptr(self.exp_avg_sq),
                    self.n, self.n_let, self.n_scale, self.truncate_thr, int(self.clear_grads_in_step), self.let_lr,
                    self.lwc_lr, self.betas[0], self.betas[1], self.eps, self.wd, C.fptr(self.step_count), C.fptr(self.norm),
-                   C.fptr(self._ws), C.stream())
+                   C.fptr(self._ws), C.fptr(self._log_loss) if self.step_log is not None else None, C.fptr(self.step_log),
+                   (self.step_log.numel() - 1) // 2 if self.step_log is not None else 0, C.stream())
             self._grads_clean = self.clear_grads_in_step
             self._scales_truncated = True
             return self.norm[0]

@@ -388,10 +388,18 @@ def test_stacked_sibling_gemms_leave_the_calibration_unchanged(monkeypatch):
                                         sh if kw["let"] else None, use_graph=True))
         la, lb = outs[0]["losses"], outs[1]["losses"]
         assert all(math.isfinite(v) for v in la + lb)
-        assert abs(la[0] - lb[0]) <= 0.02 * abs(la[0]) and abs(la[-1] - lb[-1]) <= 0.05 * abs(la[-1]), (la, lb)
+        # the forward of a stacked GEMM is bit-identical to the separate ones (same contraction order per output element; on the
+        # integer path the same int32 accumulators): the FIRST loss is equal
+        assert la[0] == lb[0], (la[0], lb[0])
+        assert abs(la[-1] - lb[-1]) <= 0.05 * abs(la[-1]), (la, lb)
         for k_ in outs[0]["omni"]:
             a, b = outs[0]["omni"][k_].float(), outs[1]["omni"][k_].float()
-            # (AdamW's first updates are sign-like: a gradient of noise magnitude flips an element by 2 * lr per step)
+            # AdamW's first updates are sign-like: an element whose gradient is of noise magnitude moves by up to 2 * lr per step in
+            # opposite directions.  The bound is the ORACLE's own sensitivity on this very problem (same block, 3 samples x 2
+            # epochs): two CPU calibrations whose inputs differ by one bf16 ulp end 4.1e-3 .. 4.5e-3 apart on fc1_smooth_shift,
+            # 4.7e-3 .. 5.3e-3 on out_smooth_scale / qkt_smooth_scale (mean |delta|; tests/diag/adam_spread.py).  The two
+            # schedules compared here differ by less: the siblings' input gradients summed in fp32 instead of as bf16 terms
+            # (measured 3.0e-3 on fc1_smooth_shift, the worst tensor).
             assert float((a - b).abs().mean()) <= 5e-3 + 0.02 * float(a.abs().mean()), k_
 
 

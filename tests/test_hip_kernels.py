@@ -375,10 +375,15 @@ def test_adamw_step_fused_vs_torch():
     p = p0.clone().to(DEV)
     m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
     step, norm, ws = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV), torch.zeros(512, device=DEV)
+    loss_t = torch.zeros(1, device=DEV)
+    log = torch.zeros(1 + 2 * 4, device=DEV)           # room for 4 of the 7 steps: the rest must only be counted
+    logged = []
 
     def fused(gd):
+        loss_t.fill_(float(len(logged)) + 0.5)
         C.call("oq_adamw_step", C.fptr(p), C.fptr(gd), C.fptr(m), C.fptr(v), n, n_let, n_tr, thr, 1, 5e-3, 1e-2, 0.9, 0.999,
-               1e-8, 0.01, C.fptr(step), C.fptr(norm), C.fptr(ws), C.stream())
+               1e-8, 0.01, C.fptr(step), C.fptr(norm), C.fptr(ws), C.fptr(loss_t), C.fptr(log), 4, C.stream())
+        logged.append((float(loss_t), float(norm[0])))
 
     for it in range(6):
         gr = torch.randn(n, generator=g) * (10.0 ** (it - 3))
@@ -410,6 +415,11 @@ def test_adamw_step_fused_vs_torch():
     p.copy_(p_snap); m.copy_(m_snap); v.copy_(v_snap); step.copy_(s_snap)
     fused(g2)
     assert torch.equal(p, p1) and float(step) == 7.0
+    # the on-device step log: every call counted (skipped and repeated ones too), the first 4 recorded as (loss, norm)
+    host = log.tolist()
+    assert host[0] == float(len(logged)) == 9.0
+    for k in range(4):
+        assert host[1 + 2 * k] == logged[k][0] and host[2 + 2 * k] == logged[k][1]
 
 
 @pytest.mark.parametrize("direct", ["1", "0"])
@@ -1185,3 +1195,23 @@ def test_sibling_gradients_are_summed_inside_the_norm_backward():
     assert sib0 is None
     assert float((gx1 - gx0).abs().max()) <= 1e-5 * float(gx0.abs().max())
     assert float((gw1 - gw0).abs().max()) <= 1e-5 * float(gw0.abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("bs,T,nkv,rep,hd", [(1, 256, 8, 8, 128), (2, 33, 2, 4, 64), (1, 5, 1, 3, 8)])
+def test_group_sum_gqa(dtype, bs, T, nkv, rep, hd):
+    """oq_group_sum: dK / dV of a shared key-value head = sum over its query heads (backward of repeat_kv,
+    models/int_llama_layer.py:136-141), fp32 accumulation in head order, both tensors in one launch."""
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(bs + T + rep)
+    a = torch.randn(bs, T, nkv * rep, hd, generator=g).to(dtype).to(DEV)
+    b = torch.randn(bs, T, nkv * rep, hd, generator=g).to(dtype).to(DEV)
+    ya, yb = ops.group_sum(a, nkv, rep, b)
+    for x, y in ((a, ya), (b, yb)):
+        want = x.float().view(bs, T, nkv, rep, hd)
+        acc = want[:, :, :, 0].clone()
+        for r in range(1, rep):
+            acc = acc + want[:, :, :, r]
+        assert torch.equal(y, acc.to(dtype))
+    (y1, none) = ops.group_sum(a, nkv, rep)
+    assert none is None and torch.equal(y1, ya)
