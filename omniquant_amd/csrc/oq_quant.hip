@@ -852,6 +852,10 @@ extern "C" int oq_fakequant_fwd(const void* w, int w_dtype, int64_t rows, int64_
         oq_set_error("oq_fakequant_fwd: integer codes requested but the wave-per-row kernels did not take the problem");
         return OQ_E_UNSUPPORTED;
     }
+    if (oq_groupq_eligible(p, false)) {     // grouped weights without LET: the lanes-per-group kernels (oq_groupq.hip)
+        const int gq = oq_groupq_fwd(p, w_dtype, y_dtype, stream);
+        if (gq <= 0) return gq;
+    }
     const bool let = col_mul || row_div || row_mul || shift;
     int ch, bt;
     row_geometry(cols, 2, &ch, &bt);
@@ -963,6 +967,10 @@ extern "C" int oq_fakequant_bwd(const void* w, int w_dtype, int64_t rows, int64_
             }
             return OQ_OK;
         }
+    }
+    if (oq_groupq_eligible(p, true)) {      // grouped frozen weights without LET: the lanes-per-group kernels (oq_groupq.hip)
+        const int gq = oq_groupq_bwd(p, w_dtype, g_dtype, stream);
+        if (gq <= 0) return gq;
     }
     // the LET instantiation is needed whenever the transform is present (x must be recomputed), not only for its grads
     const bool let = col_mul || row_div || row_mul || g_col_mul || g_shift || g_row_div || g_row_mul;

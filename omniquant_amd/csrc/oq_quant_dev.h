@@ -245,3 +245,9 @@ int64_t oq_letq_bwd_blocks(int64_t rows);
 int oq_letq_fwd_multi(const FQ* ps, int n, int w_dtype, int y_dtype, void* stream);
 int oq_letq_bwd_multi(FQ* ps, int n, int w_dtype, int g_dtype, const int64_t* workspace_floats, int64_t* parts, void* stream);
 int64_t oq_rowq_bwd_blocks(int64_t rows, int64_t cols);     // workgroups that write column partials (workspace rows)
+
+// lanes-per-group kernels for grouped weights without LET (oq_groupq.hip).  oq_groupq_fwd / _bwd return OQ_OK when launched,
+// 1 when the dtype pair is not theirs, negative on error.
+bool oq_groupq_eligible(const FQ& p, bool backward);
+int oq_groupq_fwd(const FQ& p, int w_dtype, int y_dtype, void* stream);
+int oq_groupq_bwd(const FQ& p, int w_dtype, int g_dtype, void* stream);

@@ -1,4 +1,5 @@
 """OmniLayerNorm / OmniLlamaRMSNorm on the HIP path.  Surface = reference quantize/omni_norm.py:11-63."""
+import torch
 import torch.nn as nn
 
 from . import ops
@@ -15,6 +16,20 @@ def _plain_act_quantizer(lin):
     return q
 
 
+def _f32_cached(mod, name):
+    """float32 copy of a frozen (fp16) norm weight / bias buffer, cached on the module: the LWC-only configurations read the
+    raw norm parameters every step, and a per-step cast would be a launch of another library inside the captured step."""
+    t = getattr(mod, name, None)
+    if t is None or t.dtype == torch.float32:
+        return t
+    cache = mod.__dict__.setdefault("_f32_cache", {})
+    key = (t.data_ptr(), t._version, t.dtype)
+    hit = cache.get(name)
+    if hit is None or hit[0] != key:
+        cache[name] = hit = (key, t.detach().float().contiguous())
+    return hit[1]
+
+
 class _FusedQuantMixin:
     def forward_quant(self, x, lin, is_ln, eps):
         """(fake_quant(norm(x)), x, sibling-gradient collector) through the fused kernels when `lin`'s input quantiser
@@ -25,7 +40,7 @@ class _FusedQuantMixin:
         if self.use_temporary_parameter:
             weight, bias = self.temp_weight, self.temp_bias
         else:
-            weight, bias = self.weight, (self.bias if hasattr(self, "bias") else None)
+            weight, bias = _f32_cached(self, "weight"), _f32_cached(self, "bias")
         # integer side channel for the int8 fprop of the linears that read y (ops.IntCodes), when they can use it
         stash = {"want_int": True} if (lin.use_temporary_parameter and lin.int_fprop_eligible(x.dtype)) else {}
         y, res = ops.NormQuantFn.apply(x, weight, bias, eps, is_ln, q.n_bits, stash)
@@ -53,7 +68,7 @@ class OmniLayerNorm(_FusedQuantMixin, nn.Module):
         if self.use_temporary_parameter:
             weight, bias = self.temp_weight, self.temp_bias
         else:
-            weight, bias = self.weight, self.bias
+            weight, bias = _f32_cached(self, "weight"), _f32_cached(self, "bias")
         return ops.NormFn.apply(x, weight, bias, self.eps, True)
 
     def forward_with_residual(self, x):
@@ -61,7 +76,7 @@ class OmniLayerNorm(_FusedQuantMixin, nn.Module):
         if self.use_temporary_parameter:
             weight, bias = self.temp_weight, self.temp_bias
         else:
-            weight, bias = self.weight, self.bias
+            weight, bias = _f32_cached(self, "weight"), _f32_cached(self, "bias")
         return ops.NormResidualFn.apply(x, weight, bias, self.eps, True)
 
     def set_quant_state(self, use_weight_quant, use_act_quant):
@@ -80,7 +95,7 @@ class OmniLlamaRMSNorm(_FusedQuantMixin, nn.Module):
         if self.use_temporary_parameter:
             weight, bias = self.temp_weight, self.temp_bias
         else:
-            weight, bias = self.weight, self.bias if hasattr(self, "bias") else None
+            weight, bias = _f32_cached(self, "weight"), _f32_cached(self, "bias")
         return ops.NormFn.apply(hidden_states, weight, bias, self.variance_epsilon, False)
 
     def forward_with_residual(self, hidden_states):
@@ -88,5 +103,5 @@ class OmniLlamaRMSNorm(_FusedQuantMixin, nn.Module):
         if self.use_temporary_parameter:
             weight, bias = self.temp_weight, self.temp_bias
         else:
-            weight, bias = self.weight, self.bias if hasattr(self, "bias") else None
+            weight, bias = _f32_cached(self, "weight"), _f32_cached(self, "bias")
         return ops.NormResidualFn.apply(hidden_states, weight, bias, self.variance_epsilon, False)

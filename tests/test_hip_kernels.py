@@ -1215,3 +1215,39 @@ def test_group_sum_gqa(dtype, bs, T, nkv, rep, hd):
         assert torch.equal(y, acc.to(dtype))
     (y1, none) = ops.group_sum(a, nkv, rep)
     assert none is None and torch.equal(y1, ya)
+
+
+@pytest.mark.parametrize("rows,cols,seg", [(4096, 4096, 128), (300, 11008, 128), (1024, 8192, 64), (77, 1024, 32), (64, 2048, 256),
+                                           (16, 4096, 512), (5, 128, 64)])
+@pytest.mark.parametrize("nbits,symmetric", [(3, False), (2, False), (4, True)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_groupq_kernels_match_segment_kernels(monkeypatch, rows, cols, seg, nbits, symmetric, out_dtype):
+    """Grouped weights without LET on the lanes-per-group kernels (oq_groupq.hip) vs the round-1 segment kernels (OQ_GROUPQ=0,
+    themselves pinned by the reference's G1 vectors): forward bit-identical (same helper arithmetic), LWC gradients equal up
+    to the summation order inside a group.  Includes a constant group (scale 0 -> NaN group, quirk Q1) and a NaN input."""
+    from omniquant_amd import ops
+    g = torch.Generator().manual_seed(rows + cols + seg + nbits)
+    w = (torch.randn(rows, cols, generator=g) * 0.02).half()
+    w[0, :seg] = 0.125                       # constant group
+    if rows > 2:
+        w[2, seg + 3] = float("nan")
+    nseg = rows * (cols // seg)
+    up = (4.0 + 0.5 * torch.randn(nseg, 1, generator=g))
+    low = (4.0 + 0.5 * torch.randn(nseg, 1, generator=g))
+    gy = torch.randn(rows, cols, generator=g).to(out_dtype)
+    res = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("OQ_GROUPQ", flag)
+        u, l = up.clone().to(DEV).requires_grad_(True), low.clone().to(DEV).requires_grad_(True)
+        stash = {}
+        y, _ = ops.FakeQuantFn.apply(w.to(DEV), None, None, None, None, u, l, nbits, seg, symmetric, out_dtype, stash)
+        y.backward(gy.to(DEV))
+        res.append((y.detach(), stash["scale"], stash["zp"], u.grad, l.grad))
+    (y0, s0, z0, gu0, gl0), (y1, s1, z1, gu1, gl1) = res
+    same = lambda a, b: torch.equal(torch.nan_to_num(a.float(), nan=7.0), torch.nan_to_num(b.float(), nan=7.0))
+    assert same(y0, y1) and same(s0, s1) and same(z0, z1)
+    ok = torch.isfinite(gu0) & torch.isfinite(gl0)
+    assert torch.equal(ok, torch.isfinite(gu1) & torch.isfinite(gl1))
+    for a, b in ((gu0, gu1), (gl0, gl1)):
+        d = (a[ok] - b[ok]).abs().max()
+        assert float(d) <= 2e-5 * float(a[ok].abs().max()) + 1e-12, float(d)
