@@ -302,7 +302,7 @@ int oq_copy_samples(int n, const void* src0, void* dst0, const void* src1, void*
 /* ---- optimiser (utils.py:11-24,32-46; torch.optim.AdamW at quantize/omniquant.py:207-208;
  *      models/transformation.py:5-20 truncate_number) ----------------------------------------------------
  * Learnables of a block live in ONE flat f32 arena: [0,n_let) LET params (lr_let), [n_let,n) LWC (lr_lwc).
- * oq_gradnorm: norm_out[0] = ||g||_2 (f32), norm_out[1] = 1.0 if every element is finite else 0.0.
+ * oq_gradnorm: norm_out[0] = ||g||_2 (f32), norm_out[1] = 1.0 if every element is finite else 0.0; workspace: 2048 floats.
  * oq_adamw: torch.optim.AdamW update with bias correction for `step` (read from step_ptr[0], f32 counter
  *   kept on device so the call is graph-replayable; incremented by the kernel when the step is applied).
  *   The update is skipped (GradScaler semantics, utils.py:42-43) when norm[1]==0.
@@ -317,7 +317,7 @@ int oq_adamw(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_
  * when the gradients are finite), then AdamW (as oq_adamw, reading the advanced counter) which also applies truncate_number
  * (models/transformation.py:5-20, threshold truncate_thr) to the first n_truncate parameters -- the LET scales, what the
  * reference does at the top of the NEXT step (models/int_llama_layer.py:281-284) -- and clears g when zero_grads != 0
- * (the optimizer.zero_grad() of quantize/omniquant.py:225, moved behind the update).  workspace: 512 floats.
+ * (the optimizer.zero_grad() of quantize/omniquant.py:225, moved behind the update).  workspace: 2048 floats.
  * step_log (optional, 1 + 2 * step_log_len floats): the per-step record the reference reads back with loss.item() /
  * norm.cpu() every step (quantize/omniquant.py:223-231) kept on the device instead -- step_log[0] counts the steps logged
  * since the host last zeroed it, entry k is (loss[0], gradient norm) of step k (written while k < step_log_len; `loss` may be

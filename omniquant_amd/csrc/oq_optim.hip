@@ -11,10 +11,33 @@ namespace {
 __global__ void __launch_bounds__(256) gradnorm_partial_kernel(const float* g, int64_t n, float* ws) {
     __shared__ float red[2][4];
     float ss = 0.f, bad = 0.f;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = g[i];
+    // 16-byte loads, four in flight per thread (a grouped 70B block has 27 M learnables: 107 MB of gradients per step);
+    // the arena is 16-byte aligned (a fresh allocation) and the tail is walked element-wise
+    const int64_t n4 = (reinterpret_cast<uintptr_t>(g) & 15u) == 0 ? n / 4 : 0;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const f32x4 a = g4[i], b = g4[i + stride], c = g4[i + 2 * stride], d = g4[i + 3 * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ss += a[k] * a[k]; ss += b[k] * b[k]; ss += c[k] * c[k]; ss += d[k] * d[k];
+            if (!(fabsf(a[k]) <= 3.4028234663852886e38f) || !(fabsf(b[k]) <= 3.4028234663852886e38f) ||
+                !(fabsf(c[k]) <= 3.4028234663852886e38f) || !(fabsf(d[k]) <= 3.4028234663852886e38f)) bad = 1.f;   // NaN or inf
+        }
+    }
+    for (; i < n4; i += stride) {
+        const f32x4 a = g4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ss += a[k] * a[k];
+            if (!(fabsf(a[k]) <= 3.4028234663852886e38f)) bad = 1.f;
+        }
+    }
+    for (int64_t j = n4 * 4 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; j < n; j += stride) {
+        const float v = g[j];
         ss += v * v;
-        if (!(fabsf(v) <= 3.4028234663852886e38f)) bad = 1.f;   // NaN or inf
+        if (!(fabsf(v) <= 3.4028234663852886e38f)) bad = 1.f;
     }
     ss = wave_sum(ss);
     bad = wave_max(bad);
@@ -131,7 +154,7 @@ __global__ void truncate_kernel(float* x, int64_t n, float thr) {
     }
 }
 
-constexpr int GN_BLOCKS = 256;
+constexpr int GN_BLOCKS = 1024;
 }  // namespace
 
 extern "C" int oq_gradnorm(const float* g, int64_t n, float* norm_out, float* workspace, void* stream) {

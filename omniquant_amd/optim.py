@@ -88,7 +88,7 @@ class BlockOptimizer:
         self.exp_avg_sq = torch.zeros_like(self.grad)
         self.step_count = torch.zeros(1, dtype=torch.float32, device=dev)
         self.norm = torch.zeros(2, dtype=torch.float32, device=dev)
-        self._ws = torch.zeros(512, dtype=torch.float32, device=dev)
+        self._ws = torch.zeros(2048, dtype=torch.float32, device=dev)      # oq_adamw_step / oq_gradnorm workspace
         self.collector = GradCollector()
         off = 0
         with torch.no_grad():

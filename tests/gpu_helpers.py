@@ -161,8 +161,13 @@ def oracle_step_bf16_model(g, meta):
     bf = torch.bfloat16
     x, tgt, mask = T(g["x"]).to(bf).float(), T(g["target"]).to(bf).float(), T(g["mask"])
     pos = torch.from_numpy(g["position_ids"])
-    temps = blk.temporaries(store_dtype=bf)
-    out = blk.forward(x, mask, pos, temps=temps, act_quant=True, act_dtype=bf)
+    from omniquant_amd import ops
+    cols = [v.shape[1] for k, v in g.items() if k.startswith("w.") and k.endswith("proj.weight")]
+    # the product's integer fprop (oq_gemm_i8) runs when its quantiser kernels can emit codes for these row lengths
+    use_int = (ops.int_fprop_on() and meta["abits"] <= 8 and meta["wbits"] <= 8 and not meta["group_size"]
+               and all(c % 16 == 0 and ops.int_codes_supported(c, c, meta["wbits"], False) for c in cols))
+    temps = blk.temporaries(store_dtype=bf, int_fprop=use_int)
+    out = blk.forward(x, mask, pos, temps=temps, act_quant=True, act_dtype=bf, int_fprop=use_int)
     loss = torch.nn.functional.mse_loss(tgt, out)
     loss.backward()
     return float(loss.detach()), {n: p.grad.detach().clone() for n, p in blk.params.items()}

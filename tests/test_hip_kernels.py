@@ -325,7 +325,7 @@ def test_adamw_gradnorm_truncate_vs_torch():
     opt = torch.optim.AdamW([{"params": [pt_let], "lr": 5e-3}, {"params": [pt_lwc], "lr": 1e-2}], weight_decay=0.0)
     p = p0.clone().to(DEV)
     m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    step, norm, ws = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV), torch.zeros(512, device=DEV)
+    step, norm, ws = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV), torch.zeros(2048, device=DEV)
     for it in range(5):
         gr = torch.randn(n, generator=g) * (10.0 ** (it - 2))
         pt_let.grad, pt_lwc.grad = gr[:n_let].clone(), gr[n_let:].clone()
@@ -374,7 +374,7 @@ def test_adamw_step_fused_vs_torch():
     opt = torch.optim.AdamW([{"params": [pt_let], "lr": 5e-3}, {"params": [pt_lwc], "lr": 1e-2}], weight_decay=0.01)
     p = p0.clone().to(DEV)
     m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    step, norm, ws = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV), torch.zeros(512, device=DEV)
+    step, norm, ws = torch.zeros(1, device=DEV), torch.zeros(2, device=DEV), torch.zeros(2048, device=DEV)
     loss_t = torch.zeros(1, device=DEV)
     log = torch.zeros(1 + 2 * 4, device=DEV)           # room for 4 of the 7 steps: the rest must only be counted
     logged = []
