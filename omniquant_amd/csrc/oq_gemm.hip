@@ -684,6 +684,188 @@ __global__ void __launch_bounds__(512) gemm_bf16_p3_kernel(GemmP p) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 256x256x32 kernel for the WEIGHT-GRADIENT products (dW = dY^T X: both operands k-strided, short contraction K = tokens,
+// huge output): the 256x128x64 kernel pays 48 one-KiB LDS-DMA pieces and 16 fragment reads per wave for every 32 MFMAs, and at
+// K = 2048 its per-tile fixed costs (first K-tile's latency, epilogue start, workgroup turnover: 6-8 us) are a quarter of a
+// tile's life.  Here a workgroup owns 256x256 outputs and walks K in tiles of 32: per wave still 32 MFMAs per barrier pair
+// (64x128 outputs as 4x8 tiles, ONE k-step), but 32 pieces (4 per wave) and 12 fragment reads -- a third less staging per flop --
+// and half as many output tiles.  K-tiles of 32 keep a stage at 32 KiB, so a FOUR-stage ring (128 KiB) holds the same
+// two-tiles-ahead prefetch and staggered wave groups as the three-stage ring of the 64-deep kernel.  Epilogue through LDS in
+// two halves of the wave's 64x128 block.  Same arithmetic per output element (k ascending in steps of 32 inside the MFMA):
+// results are bit-identical to gemm_bf16_p3_kernel's.
+// ---------------------------------------------------------------------------------------------------
+constexpr int W2_BM = 256, W2_BN = 256, W2_BK = 32;
+constexpr int W2_A_BYTES = W2_BM * W2_BK * 2;      // 16 KiB
+constexpr int W2_B_BYTES = W2_BN * W2_BK * 2;      // 16 KiB
+constexpr int W2_STAGE = W2_A_BYTES + W2_B_BYTES;  // 32 KiB
+constexpr int W2_NSTAGE = 4;
+constexpr int W2_EPI_RS = 272;                     // bytes per parked row (64 fp32 + pad)
+constexpr int W2_LDS = (W2_NSTAGE * W2_STAGE > 8 * 64 * W2_EPI_RS) ? W2_NSTAGE * W2_STAGE : 8 * 64 * W2_EPI_RS;
+
+template <typename TOUT>
+__global__ void __launch_bounds__(512) gemm_bf16_w256_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[W2_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;              // wave tile: rows wm*64 .. +64, columns wn*128 .. +128
+    int tile;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    }
+    int64_t m0, n0;
+    {
+        const int W = p.blk48 > 0 ? p.blk48 : 8;        // strip-ordered ids, as in gemm_bf16_p3_kernel
+        const int ssz = p.tiles_m * W, strip = tile / ssz, rem = tile - strip * ssz;
+        const int w = p.tiles_n - strip * W < W ? p.tiles_n - strip * W : W;
+        const int mi = rem / w;
+        m0 = (int64_t)mi * W2_BM;
+        n0 = (int64_t)(strip * W + (rem - mi * w)) * W2_BN;
+    }
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.a);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.b);
+    TOUT* C = reinterpret_cast<TOUT*>(p.c);
+    // LDS-DMA pieces of this wave (1 KiB = 2 k-rows of 512 B): A pieces wid, wid + 8; B pieces wid, wid + 8
+    const bf16_t* ga[2];
+    const bf16_t* gb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        ga[q] = piece_src<false, 2 * W2_BM>(A, p.lda, m0, p.M, wid + 8 * q, lane);
+        gb[q] = piece_src<false, 2 * W2_BN>(B, p.ldb, n0, p.N, wid + 8 * q, lane);
+    }
+    const int64_t astep = (int64_t)W2_BK * p.lda, bstep = (int64_t)W2_BK * p.ldb;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint32_t ba[4], bb0[4], bb1[4];
+    frag_bases<false, 2 * W2_BM>(wm * 64, lane, ba);
+    frag_bases<false, 2 * W2_BN>(wn * 128, lane, bb0);
+    frag_bases<false, 2 * W2_BN>(wn * 128 + 64, lane, bb1);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const int nt = (int)(p.K / W2_BK);
+
+    auto issue_a = [&](int stage) {
+        char* sa = smem + stage * W2_STAGE + wid * 1024;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { glds16(ga[q], sa + q * 8192); ga[q] += astep; }
+    };
+    auto issue_b = [&](int stage, int q) {
+        char* sb = smem + stage * W2_STAGE + W2_A_BYTES + wid * 1024;
+        glds16(gb[q], sb + q * 8192);
+        gb[q] += bstep;
+    };
+    // staggered two-group schedule of gemm_bf16_p3_kernel; hazards with FOUR stages: the DMA of tile t+2 overwrites the stage
+    // of tile t-2, whose fragment reads completed two barrier pairs ago in either group.
+    const bool grp_b = wid >= 4;
+    issue_a(0); issue_b(0, 0); issue_b(0, 1);
+    if (nt > 1) {
+        issue_a(1); issue_b(1, 0); issue_b(1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (grp_b) __builtin_amdgcn_s_barrier();
+    int s_cur = 0, s_pre = 2;
+    for (int t = 0; t < nt; ++t) {
+        // ---------------- H1(t): DMA of tile t+2 (A half), fragments of tile t ----------------
+        const bool more = t + 2 < nt;
+        if (more) issue_a(s_pre);
+        const uint32_t sao = lds_base + (uint32_t)(s_cur * W2_STAGE);
+        const uint32_t sbo = sao + W2_A_BYTES;
+        bf16x8 fa[4], fb[8];
+        fa[0] = frag_read<false, 2 * W2_BM, 0, 0>(ba, sao);
+        fa[1] = frag_read<false, 2 * W2_BM, 0, 1>(ba, sao);
+        fa[2] = frag_read<false, 2 * W2_BM, 0, 2>(ba, sao);
+        fa[3] = frag_read<false, 2 * W2_BM, 0, 3>(ba, sao);
+        fb[0] = frag_read<false, 2 * W2_BN, 0, 0>(bb0, sbo);
+        fb[1] = frag_read<false, 2 * W2_BN, 0, 1>(bb0, sbo);
+        fb[2] = frag_read<false, 2 * W2_BN, 0, 2>(bb0, sbo);
+        fb[3] = frag_read<false, 2 * W2_BN, 0, 3>(bb0, sbo);
+        fb[4] = frag_read<false, 2 * W2_BN, 0, 0>(bb1, sbo);
+        fb[5] = frag_read<false, 2 * W2_BN, 0, 1>(bb1, sbo);
+        fb[6] = frag_read<false, 2 * W2_BN, 0, 2>(bb1, sbo);
+        fb[7] = frag_read<false, 2 * W2_BN, 0, 3>(bb1, sbo);
+        if (t + 1 < nt) {
+            // my four pieces of tile t+1 have landed; the two A pieces of tile t+2 just issued stay in flight
+            if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---------------- H2(t): 32 MFMAs on registers, the B half of tile t+2's DMA in between ----------------
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            if (more && i == 0) issue_b(s_pre, 0);
+            if (more && i == 2) issue_b(s_pre, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        s_cur = (s_cur + 1) & 3;
+        s_pre = (s_pre + 1) & 3;
+    }
+    if (!grp_b) __builtin_amdgcn_s_barrier();
+    // ---- epilogue through LDS, the wave's 64 x 128 block in two halves of 64 x 64 (same scheme as gemm_bf16_p3_kernel) ------
+    char* epi = smem + wid * (64 * W2_EPI_RS);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int64_t nb = n0 + wn * 128 + h * 64 + j * 16 + (lane >> 4) * 4;
+            if (p.bias && nb < p.N) bv = *reinterpret_cast<const f32x4*>(p.bias + nb);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][h * 4 + j][r] * p.alpha;
+                    if (p.bias) v[r] += bv[r];
+                }
+                *reinterpret_cast<f32x4*>(epi + (i * 16 + (lane & 15)) * W2_EPI_RS + (j * 16 + (lane >> 4) * 4) * 4) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int64_t n = n0 + wn * 128 + h * 64 + (lane & 7) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = q * 8 + (lane >> 3);
+            const int64_t m = m0 + wm * 64 + row;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(epi + row * W2_EPI_RS + (lane & 7) * 32);
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(epi + row * W2_EPI_RS + (lane & 7) * 32 + 16);
+            if (m >= p.M || n >= p.N) continue;
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            TOUT* dst = C + m * p.ldc + n;
+            if (p.addend) {
+                const TOUT* ad = reinterpret_cast<const TOUT*>(p.addend) + m * p.ldc + n;
+                float a8[8];
+                Vec8<TOUT>::load(ad, a8);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += a8[r];
+            }
+            Vec8<TOUT>::store(dst, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the second half re-uses the wave's parking region
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Persistent variant of the 256x128x64 kernel: one workgroup per CU walks a list of output tiles and the LDS-DMA
 // stream of K-tiles never drains at a tile boundary (the first K-tiles of the next output tile are already in flight
 // while the current tile finishes and stores its result).  Removes the per-tile pipeline fill, which dominated
@@ -1194,6 +1376,26 @@ static int oq_gemm_impl(const void* a, const void* bm, void* c, const float* bia
             p.epi_lds = (dbg_env_i("OQ_GEMM_EPI_LDS", 1) != 0 && N % 8 == 0 && ldc % 8 == 0 && sc_o % 8 == 0 && sc_i % 8 == 0 &&
                          (reinterpret_cast<uintptr_t>(c) & 15) == 0 && (!addend || (reinterpret_cast<uintptr_t>(addend) & 15) == 0) &&
                          (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0)) ? 1 : 0;
+            // weight-gradient shape class (both operands k-strided, one problem, at least one full round of 256 x 256 tiles):
+            // the 256x256x32 kernel
+            {
+                const int64_t tm2 = (M + W2_BM - 1) / W2_BM, tn2 = (N + W2_BN - 1) / W2_BN;
+                // rounds of the 256 CUs: a 256 x 256 tile takes ~1.76x the time of a 256 x 128 tile at K = 2048 (measured: -12 % at
+                // whole rounds); ragged last rounds decide the rest
+                const int64_t r1 = (tm3 * tn3 + 255) / 256, r2 = (tm2 * tn2 + 255) / 256;
+                const bool pays = dbg_env_i("OQ_GEMM_W256_MIN_TILES", 256) < 256 || (double)r2 * 1.76 < (double)r1 + 1e-9;
+                if (!a_kc && !b_kc && tri_mode == 0 && batch_o * batch_i == 1 && g_splitk_request <= 1 && p.epi_lds && pays &&
+                    K % W2_BK == 0 && tm2 * tn2 >= dbg_env_i("OQ_GEMM_W256_MIN_TILES", 256) && dbg_env_i("OQ_GEMM_W256", 1) != 0) {
+                    p.tiles_n = (int)tn2;
+                    p.tiles_m = (int)tm2;
+                    p.blk48 = 8;
+                    dim3 gridw((unsigned)(tm2 * tn2));
+                    if (out_dtype == OQ_F32) hipLaunchKernelGGL((gemm_bf16_w256_kernel<float>), gridw, dim3(512), 0, st, p);
+                    else hipLaunchKernelGGL((gemm_bf16_w256_kernel<bf16_t>), gridw, dim3(512), 0, st, p);
+                    OQ_CHECK_LAUNCH("oq_gemm(w256)");
+                    return OQ_OK;
+                }
+            }
             {
                 const int sw = dbg_env_i("OQ_GEMM_BLK48", 8);          // 0: plain n-/m-major order; else the strip width
                 p.blk48 = (tri_mode == 0 && sw > 0) ? (sw == 1 ? 8 : sw) : 0;

@@ -157,6 +157,37 @@ def test_gemm_strip_ordered_tiles_and_lds_epilogue_exact(a_kc, b_kc, M, N, K):
     assert torch.equal(cb.cpu().float(), (A @ B.T).bfloat16().float())
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 2048), (12288, 4096, 256), (2304, 2688, 64), (520, 3080, 96), (4096, 1032, 32),
+                                   (256, 264, 160), (11008, 4096, 128)])
+def test_gemm_weight_gradient_kernel_exact(monkeypatch, M, N, K):
+    """gemm_bf16_w256_kernel (256x256x32 tiles, four-stage LDS ring; the weight-gradient shape class: both operands
+    k-strided): exact on integer-valued operands -- full rounds, ragged M / N edges, a last strip narrower than 8 n-tiles,
+    K of 1, 2, 3, 5 and 64 K-tiles (the ring's prologue, steady state and tail), bias and the output addend -- and
+    bit-identical to the 256x128x64 kernel on random bf16 data (same contraction order per output element)."""
+    from omniquant_amd import ops
+    monkeypatch.setenv("OQ_GEMM_W256_MIN_TILES", "1")
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A = torch.randint(-3, 4, (M, K), generator=g).float()
+    B = torch.randint(-3, 4, (N, K), generator=g).float()
+    bias = torch.randint(-5, 6, (N,), generator=g).float()
+    add = torch.randint(-9, 10, (M, N), generator=g).float()
+    want = A @ B.T + bias[None, :] + add
+    a, b = A.T.contiguous().bfloat16().to(DEV), B.T.contiguous().bfloat16().to(DEV)
+    c = add.clone().to(DEV)
+    ops.gemm(a, b, c, M, N, K, M, N, N, False, False, bias=bias.to(DEV), addend=c)
+    assert torch.equal(c.cpu(), want)
+    cb = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a, b, cb, M, N, K, M, N, N, False, False)
+    assert torch.equal(cb.cpu().float(), (A @ B.T).bfloat16().float())
+    ar, br = torch.randn(K, M, generator=g).bfloat16().to(DEV), torch.randn(K, N, generator=g).bfloat16().to(DEV)
+    c1 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    c2 = torch.empty_like(c1)
+    ops.gemm(ar, br, c1, M, N, K, M, N, N, False, False)
+    monkeypatch.setenv("OQ_GEMM_W256", "0")
+    ops.gemm(ar, br, c2, M, N, K, M, N, N, False, False)
+    assert torch.equal(c1, c2)
+
+
 @pytest.mark.parametrize("a_kc,b_kc,M,N,K", [(True, False, 2048, 5120, 27648), (True, True, 2048, 5120, 15360), (False, False, 2048, 5120, 15360)])
 def test_gemm_split_contraction_exact(a_kc, b_kc, M, N, K):
     """The LLaMA-2-13B launches with N = 5120 (320 tiles of 256 x 128 = 1.25 rounds of the 256 CUs, 216-432 K-tiles long):
