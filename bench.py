@@ -224,7 +224,7 @@ def kernel_rooflines(runner, quant_inps, fp_inps, cfg, n_prof=3):
 
 
 PROFILE_COUNTERS = "r3_gemm_counters.json"
-ROOFLINE_KERNEL = "gemm_bf16_p3_kernel"
+ROOFLINE_KERNEL = "gemm_bf16_p3_kernel + gemm_bf16_w256_kernel"
 MFMA_I8_PEAK_TOPS = 5000.0         # dense int8 = 2x bf16 (MI355X_MICROARCH.md, matrix-core table)
 
 
@@ -465,7 +465,7 @@ def main():
                        "fprop_arithmetic": "int8 codes on v_mfma_i32_16x16x64_i8 (exact), fp32 epilogue" if i8 else "bf16"},
             # dominant kernel of the step: the bf16 MFMA GEMM (dgrad + wgrad of the fake-quant linears; + fprop when the integer
             # path is off).  achieved = algorithmic flops of those launches / their summed HIP-event durations.
-            "roofline": {"bound": "mfma", "kernel": ROOFLINE_KERNEL + (" (dgrad+wgrad of the fake-quant linears)" if i8 else
+            "roofline": {"bound": "mfma", "kernel": ROOFLINE_KERNEL + (" (dgrad + wgrad of the fake-quant linears)" if i8 else
                                                                        " (fprop+dgrad+wgrad of the fake-quant linears)"),
                          "achieved": b16["tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": b16["tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic, "mfma_busy_frac": mfma_busy,

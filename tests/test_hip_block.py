@@ -421,3 +421,74 @@ def test_real_quant_after_calibration():
         w = m.dequantize()
         assert w.shape == (m.outfeatures, m.infeatures) and bool(torch.isfinite(w.float()).all())
         assert m.qweight.shape == (m.infeatures // 32 * 4, m.outfeatures) and m.qzeros.shape == (m.infeatures // 64, m.outfeatures // 32 * 4)
+
+
+def test_opt_block_integer_fprop_production_step():
+    """An OPT-125m-shaped block (H 768, FFN 3072, 12 heads, biases, LayerNorm) W4A4 --lwc --let in production mode: its six
+    linears take the integer fprop (oq_gemm_i8: LayerNorm -> quantiser codes for q / k / v and fc1, per-token codes for out_proj
+    and fc2 inputs) exactly like the LLaMA block's.  One sample-step against the CPU oracle's fp32 step on the same
+    bf16-representable sample: loss, and the gradients of the MLP-side learnables (the attention-score path carries the 16-bit
+    attention's noise floor, see tests/test_fullsize_parity.py); and against the same step with the integer path switched off
+    (bf16 operands): the two must agree to bf16 accuracy in the loss."""
+    from oracle import ref_cpu as R
+    from omniquant_amd import ops
+    from omniquant_amd import synthetic as S
+    from omniquant_amd.calibrate import StepRunner, decoder_layer_class, default_args, register_let_parameters
+    from omniquant_amd.optim import BlockOptimizer
+    H, Tn = 768, 256
+    cfg = S.make_config(None, family="opt", hidden_size=H, inter=3072, heads=12, kv_heads=12)
+    layer = S.make_layer(cfg, seed=3, device="cpu")
+    weights = {n: p.detach().float() for n, p in layer.named_parameters()}
+    x = S.make_calib_inputs(1, Tn, H, dtype=torch.float32).to(torch.bfloat16).float()
+    mask = S.causal_mask(Tn)
+    sc, sh = S.synth_act_stats(cfg, 1)
+    cd = dict(hidden_size=H, num_attention_heads=12, num_key_value_heads=12)
+    blk = R.Block("opt", cd, weights, R.QuantSpec(4, 4, None, True, True), max_pos=Tn)
+    blk.register_let(sc, sh, 0.5, 0, "model.decoder.layers")
+    with torch.no_grad():
+        tgt = blk.forward(x, mask, None, None, False)
+    out = blk.forward(x, mask, None, temps=blk.temporaries(), act_quant=True)
+    loss_o = torch.nn.functional.mse_loss(tgt, out)
+    loss_o.backward()
+    ref = {n: p.grad.detach().clone() for n, p in blk.params.items()}
+    res = {}
+    import os
+    for flag in ("1", "0"):
+        os.environ["OQ_INT_FPROP"] = flag
+        try:
+            args = default_args(wbits=4, abits=4, lwc=True, let=True, net="opt-125m", nsamples=1)
+            q = decoder_layer_class("opt")(cfg, S.make_layer(cfg, seed=3, device=DEV), args).to(DEV)
+            q.compute_dtype = torch.bfloat16
+            q.set_quant_state(False, True)
+            q.let = True
+            register_let_parameters(q, "opt", sc, sh, 0.5, 0, DEV)
+            opt = BlockOptimizer(q, args.let_lr, args.lwc_lr, args.wd)
+            opt.clear_grads_in_step = False
+            used = {"n": 0}
+            orig = ops.gemm_i8
+
+            def spy(*a, **k):
+                used["n"] += 1
+                return orig(*a, **k)
+            ops.gemm_i8 = spy
+            try:
+                runner = StepRunner(q, opt, mask.to(DEV), None, (1, Tn, H), torch.bfloat16, False, False, use_graph=False)
+                runner.run(x.to(DEV).to(torch.bfloat16), tgt.to(DEV).to(torch.bfloat16))
+            finally:
+                ops.gemm_i8 = orig
+            torch.cuda.synchronize()
+            res[flag] = (float(runner.loss), {n: p.grad.detach().cpu().clone() for n, p in q.named_parameters()}, used["n"])
+        finally:
+            os.environ.pop("OQ_INT_FPROP", None)
+    assert res["1"][2] == 6 and res["0"][2] == 0, (res["1"][2], res["0"][2])          # q, k, v, out_proj, fc1, fc2
+    l_int, l_bf = res["1"][0], res["0"][0]
+    assert abs(l_int - float(loss_o)) <= 1e-2 * float(loss_o) and abs(l_int - l_bf) <= 2e-2 * l_bf, (l_int, l_bf, float(loss_o))
+    cos = {}
+    for n, g in res["1"][1].items():
+        a, b = g.double().reshape(-1), ref[n].double().reshape(-1)
+        cos[n] = float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300))
+    print({k: round(v, 4) for k, v in cos.items()})
+    for n in ("fc1_smooth_scale", "fc1_smooth_shift", "fc1.weight_quantizer.upbound_factor", "fc2.weight_quantizer.upbound_factor",
+              "fc2.weight_quantizer.lowbound_factor"):
+        assert cos[n] >= 0.985, (n, cos[n])
+    assert min(cos.values()) > 0.5 and all(torch.isfinite(g).all() for g in res["1"][1].values())

@@ -1,6 +1,7 @@
-"""profiles/r2_gemm_counters.json from rocprofv3 --pmc passes of bench.py (tools only).
+"""profiles/r3_gemm_counters.json from rocprofv3 --pmc passes of bench.py (tools only).
 
-usage: gemm_counters.py CONFIG STEPS mfma_counter_collection.csv [fetch_counter_collection.csv write_counter_collection.csv]
+usage: gemm_counters.py CONFIG STEPS HEAD mfma_counter_collection.csv [fetch_counter_collection.csv write_counter_collection.csv]
+(HEAD = the commit the passes were collected at; bench.py reports it as the provenance of roofline.traffic / mfma_busy_frac)
 
 Per launch of the linear-layer GEMM kernel inside calibration steps (launch groups that occur at least STEPS times):
   mfma_busy_frac = sum SQ_VALU_MFMA_BUSY_CYCLES / sum (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)   (MI355X_MICROARCH.md:
@@ -13,20 +14,22 @@ import json
 import sys
 
 csv.field_size_limit(1 << 30)
-KERNEL = "gemm_bf16_p3_kernel"
+KERNELS = ("gemm_bf16_p3_kernel", "gemm_bf16_w256_kernel")      # dgrad / wgrad of the fake-quant linears
+KERNEL = " + ".join(KERNELS)
 
 
 def load(path, counters):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     for r in csv.DictReader(open(path)):
-        if KERNEL in r["Kernel_Name"] and r["Counter_Name"] in counters:
+        if any(k in r["Kernel_Name"] for k in KERNELS) and r["Counter_Name"] in counters:
             a = agg[(r["Kernel_Name"][:90], r["Grid_Size"])][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
     return agg
 
 
-cfg, steps = sys.argv[1], int(sys.argv[2])
+cfg, steps, head = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+sys.argv = sys.argv[:3] + sys.argv[4:]
 m = load(sys.argv[3], {"SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_INSTS_MFMA"})
 m = {k: v for k, v in m.items() if v["SQ_VALU_MFMA_BUSY_CYCLES"][0] >= steps}
 busy = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"][1] for v in m.values())
@@ -50,4 +53,4 @@ if len(sys.argv) > 5:
     write = sum(v["WRITE_SIZE"][1] for v in w.values()) * 1024.0 / nw
     out.update({"fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "bytes_per_launch": fetch + write})
     out["method"] += "; FETCH_SIZE and WRITE_SIZE in two further separate passes, FETCH_SIZE x2 (gfx950), KiB -> bytes"
-print(json.dumps({cfg: out}, indent=1))
+print(json.dumps({"_head": head, cfg: out}, indent=1))
