@@ -85,7 +85,9 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
     int par = 0;
     // integer side channel (FQ::codes / csum): the row's code sum needs one more row-wide reduction; with several waves per row
     // it rides in the free slot of the NEXT row's min / max exchange (no extra barrier per row), flushed once after the loop
-    const bool want_codes = !LET && p.codes != nullptr;
+    // (LET rows use the exchange's fourth slot for w @ shift: their code sum takes an exchange of its own -- the row-group
+    // kernels serve the LET weights of the benchmarked widths, this path only the narrow and the very wide ones)
+    const bool want_codes = p.codes != nullptr;
     const bool eight = p.nbits == 8;
     int64_t pend_r = -1;
     float pend_v = 0.f;
@@ -144,7 +146,7 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
         if (nw > 1) {
             const int op[4] = {1, 2, 1, 0};
             row_exchange(red, par, wid, rslot, nw, lane, v4, op);
-            if (want_codes && pend_r >= 0 && wsub == 0) p.csum[pend_r] = v4[3];     // the previous row's code sum
+            if (!LET && want_codes && pend_r >= 0 && wsub == 0) p.csum[pend_r] = v4[3];     // the previous row's code sum
         }
         hi = v4[0]; lo = v4[1];
         const float bad = v4[2];
@@ -230,11 +232,20 @@ __global__ void __launch_bounds__(512) rowq_fwd_kernel(FQ p, int nw, int chn) {
         if (want_codes) {
             // a row whose scale is 0 / NaN is all-NaN in the reference (quirk Q1): a NaN code sum makes the integer GEMM say so
             const float cs = (regular && p.nbits < 16) ? wave_sum(csl) : NAN;
-            if (nw > 1) { pend_r = r; pend_v = cs; }
-            else p.csum[r] = cs;
+            if (nw == 1) {
+                p.csum[r] = cs;
+            } else if (LET) {
+                float c4[4] = {0.f, 0.f, 0.f, cs};
+                const int opc[4] = {1, 2, 1, 0};
+                row_exchange(red, par, wid, rslot, nw, lane, c4, opc);
+                if (wsub == 0) p.csum[r] = c4[3];
+            } else {
+                pend_r = r;
+                pend_v = cs;
+            }
         }
     }
-    if (want_codes && nw > 1) {       // flush the last row's code sum (every wave of the workgroup walked the same number of rows)
+    if (!LET && want_codes && nw > 1) {       // flush the last row's code sum (every wave of the workgroup walked the same number of rows)
         float v4[4] = {0.f, 0.f, 0.f, pend_v};
         const int op[4] = {1, 2, 1, 0};
         row_exchange(red, par, wid, rslot, nw, lane, v4, op);
@@ -1243,9 +1254,11 @@ int oq_letq_bwd_multi(FQ* ps, int n, int w_dtype, int g_dtype, const int64_t* wo
 // weights on the row-group kernels, everything else on the wave-per-row kernel without LET.
 extern "C" int64_t oq_fakequant_codes_supported(int64_t cols, int64_t seg, int nbits, int let) {
     if (seg != cols || nbits < 2 || nbits > 8 || env_i("OQ_ROWQ", 1) == 0) return 0;
-    if (let) return letq_ch(cols) != 0 ? 1 : 0;
+    if (let && letq_ch(cols) != 0) return 1;
+    if (let && env_i("OQ_ROWQ_FWD_LET", 1) == 0) return 0;
     RowGeo g;
-    return row_geo(cols, (int)env_i("OQ_ROWQ_FWD_NW", cols >= 8192 ? 8 : 0), &g) ? 1 : 0;
+    if (!row_geo(cols, (int)env_i("OQ_ROWQ_FWD_NW", cols >= 8192 ? 8 : 0), &g)) return 0;
+    return sizeof(float) * ((let ? 2 * cols : 0) + 64) <= LDS_BUDGET ? 1 : 0;
 }
 
 int oq_rowq_fwd(const FQ& p, int w_dtype, int y_dtype, void* stream) {

@@ -70,7 +70,9 @@ class QuantLinear(nn.Module):
                 and not aq.group_size and aq.metric != "fix0to1" and aq.dynamic_method == "per_token"
                 and wq.enable and 2 <= wq.n_bits <= 8 and not wq.group_size and wq.metric != "fix0to1"
                 and self.in_features % 16 == 0
-                and ops.int_codes_supported(self.in_features, self.in_features, wq.n_bits, False))
+                # (the weight may or may not be LET-transformed: its quantiser must be able to emit codes either way)
+                and ops.int_codes_supported(self.in_features, self.in_features, wq.n_bits, False)
+                and ops.int_codes_supported(self.in_features, self.in_features, wq.n_bits, True))
 
     def quantize_input(self, input):
         """Per-token fake quant of the input, exposed so that sibling projections reading the SAME tensor with

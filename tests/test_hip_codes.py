@@ -45,7 +45,8 @@ def test_per_token_codes(rows, cols, nbits, dtype):
     assert torch.equal(torch.nan_to_num(y0.float()), torch.nan_to_num(y.float()))
 
 
-@pytest.mark.parametrize("rows,cols", [(4096, 4096), (301, 4096), (64, 5120), (11008, 4096), (3, 4096)])
+@pytest.mark.parametrize("rows,cols", [(4096, 4096), (301, 4096), (64, 5120), (11008, 4096), (3, 4096), (768, 768), (130, 2048),
+                                       (17, 8192), (5, 512)])
 @pytest.mark.parametrize("mode", ["lwc", "let_rd", "let_rm", "let_plain"])
 @pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
 def test_weight_codes(rows, cols, mode, out_dtype):
