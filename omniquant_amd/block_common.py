@@ -153,7 +153,9 @@ class QuantBlockMixin:
         dest = self._weight_slabs(nm, out_dtype) if stack else {}
 
         def quant(mod, sp):
-            want_int = stack and mod.int_fprop_eligible(out_dtype)      # + integer codes for the int8 fprop (ops.IntCodes)
+            # + integer codes for the int8 fprop (ops.IntCodes): of the step's temporaries, and of the FOLDED weights (float32
+            # values, same codes) for the propagate pass that follows the fold
+            want_int = mod.int_fprop_eligible(out_dtype if stack else self.compute_dtype)
             if sp.shift is not None:
                 return mod.weight_quantizer.quantize(mod.weight, out_dtype=out_dtype, col_mul=sp.col_mul,
                                                      row_div=sp.row_div, row_mul=sp.row_mul, shift=sp.shift, out=dest.get(mod),
@@ -292,7 +294,8 @@ class QuantBlockMixin:
                 mod.use_temporary_parameter = False
         else:
             for mod in self._quant_linears():
-                mod.weight = mod.weight_quantizer.quantize(mod.weight, out_dtype=torch.float32)
+                mod.weight = mod.weight_quantizer.quantize(mod.weight, out_dtype=torch.float32,
+                                                           want_int=mod.int_fprop_eligible(self.compute_dtype))
                 mod.use_temporary_parameter = False
         for ln in (nm["ln1"], nm["ln2"]):
             ln.use_temporary_parameter = False

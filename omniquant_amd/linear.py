@@ -55,6 +55,9 @@ class QuantLinear(nn.Module):
         key = (w.data_ptr(), w._version, dtype)
         if self._wcache_key != key:
             self._wcache, self._wcache_key = ops.cast(w, dtype), key
+            ic = getattr(w, "_oq_int", None)          # a folded weight keeps the integer codes of its fold (block_common)
+            if ic is not None:
+                self._wcache._oq_int = ic
         return self._wcache
 
     def drop_cache(self):
@@ -69,10 +72,15 @@ class QuantLinear(nn.Module):
                 and self.use_act_quant and aq is not None and not self.disable_input_quant and aq.enable and 2 <= aq.n_bits <= 8
                 and not aq.group_size and aq.metric != "fix0to1" and aq.dynamic_method == "per_token"
                 and wq.enable and 2 <= wq.n_bits <= 8 and not wq.group_size and wq.metric != "fix0to1"
-                and self.in_features % 16 == 0
+                and self.in_features % 128 == 0 and self.out_features % 8 == 0      # the int8 MFMA kernel's K-tile / store width
                 # (the weight may or may not be LET-transformed: its quantiser must be able to emit codes either way)
                 and ops.int_codes_supported(self.in_features, self.in_features, wq.n_bits, False)
                 and ops.int_codes_supported(self.in_features, self.in_features, wq.n_bits, True))
+
+    def weight_has_codes(self):
+        """The weight this forward will use carries integer codes: the step's temporaries do when the linear is eligible
+        (block_common asks their quantisers for them), a folded weight does when its fold produced them."""
+        return self.use_temporary_parameter or getattr(self.weight, "_oq_int", None) is not None
 
     def quantize_input(self, input):
         """Per-token fake quant of the input, exposed so that sibling projections reading the SAME tensor with
@@ -81,7 +89,7 @@ class QuantLinear(nn.Module):
         if self.use_act_quant and not self.disable_input_quant:
             aq = self.act_quantizer
             if (input.is_cuda and aq.dynamic_method == "per_token" and aq.metric != "fix0to1" and not aq._identity()
-                    and self.int_fprop_eligible(input.dtype) and self.use_temporary_parameter):
+                    and self.int_fprop_eligible(input.dtype) and self.weight_has_codes()):
                 return aq.quantize(input, want_int=True)          # + integer codes for the int8 fprop (same values)
             return aq(input)
         return input

@@ -55,7 +55,7 @@ class QuantLlamaMLP(nn.Module):
                 wints = (getattr(wg, "_oq_int", None), getattr(wu, "_oq_int", None))
                 if xint is None or any(w is None for w in wints) or not ops.int_fprop_on():
                     xint = wints = None
-                stash = {"want_int": True} if (nb and self.down_proj.use_temporary_parameter
+                stash = {"want_int": True} if (nb and self.down_proj.weight_has_codes()
                                                and self.down_proj.int_fprop_eligible(xq.dtype)) else {}
                 act = ops.StackedGateUpFn.apply(xq, wg, bg, wu, bu, nb, stash, sib, xint, wints)
                 if nb:
@@ -66,7 +66,7 @@ class QuantLlamaMLP(nn.Module):
         gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq, sib)
         if fuse_q and ops.silu_mul_quant_supported(gate, dq.n_bits):
             # act_fn(gate) * up and the down_proj input quantiser in ONE kernel: the product is never stored
-            stash = {"want_int": True} if (self.down_proj.use_temporary_parameter
+            stash = {"want_int": True} if (self.down_proj.weight_has_codes()
                                            and self.down_proj.int_fprop_eligible(gate.dtype)) else {}
             act = ops.SiluMulQuantFn.apply(gate, up, dq.n_bits, stash)
             dq.scale, dq.round_zero_point = stash["scale"], stash["zp"]

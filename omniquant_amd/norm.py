@@ -42,7 +42,7 @@ class _FusedQuantMixin:
         else:
             weight, bias = _f32_cached(self, "weight"), _f32_cached(self, "bias")
         # integer side channel for the int8 fprop of the linears that read y (ops.IntCodes), when they can use it
-        stash = {"want_int": True} if (lin.use_temporary_parameter and lin.int_fprop_eligible(x.dtype)) else {}
+        stash = {"want_int": True} if (lin.weight_has_codes() and lin.int_fprop_eligible(x.dtype)) else {}
         y, res = ops.NormQuantFn.apply(x, weight, bias, eps, is_ln, q.n_bits, stash)
         q.scale, q.round_zero_point = stash["scale"], stash["zp"]
         if stash.get("int") is not None:

@@ -165,7 +165,8 @@ def oracle_step_bf16_model(g, meta):
     cols = [v.shape[1] for k, v in g.items() if k.startswith("w.") and k.endswith("proj.weight")]
     # the product's integer fprop (oq_gemm_i8) runs when its quantiser kernels can emit codes for these row lengths
     use_int = (ops.int_fprop_on() and meta["abits"] <= 8 and meta["wbits"] <= 8 and not meta["group_size"]
-               and all(c % 16 == 0 and ops.int_codes_supported(c, c, meta["wbits"], False) for c in cols))
+               and all(c % 128 == 0 and ops.int_codes_supported(c, c, meta["wbits"], False) and ops.int_codes_supported(c, c, meta["wbits"], True)
+                       for c in cols))
     temps = blk.temporaries(store_dtype=bf, int_fprop=use_int)
     out = blk.forward(x, mask, pos, temps=temps, act_quant=True, act_dtype=bf, int_fprop=use_int)
     loss = torch.nn.functional.mse_loss(tgt, out)

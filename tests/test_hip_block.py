@@ -492,3 +492,59 @@ def test_opt_block_integer_fprop_production_step():
               "fc2.weight_quantizer.lowbound_factor"):
         assert cos[n] >= 0.985, (n, cos[n])
     assert min(cos.values()) > 0.5 and all(torch.isfinite(g).all() for g in res["1"][1].values())
+
+
+def test_propagate_pass_runs_the_integer_fprop_on_folded_weights(monkeypatch):
+    """After the fold (models/int_llama_layer.py:315-332) the propagate pass (quantize/omniquant.py:242-245) forwards the
+    calibration bank through the folded block with activation quantisation on.  The fold keeps the integer codes of the
+    fake-quantised weights, so that pass runs every Linear's product on oq_gemm_i8 as well -- exact, where a cast of the folded
+    fp32 weights to bf16 would round them.  Seven integer GEMMs per forward (q, k, v separately: folded weights are not
+    stacked), and the result agrees with the bf16-operand pass to bf16 accuracy."""
+    from omniquant_amd import ops
+    from omniquant_amd import synthetic as S
+    from omniquant_amd.calibrate import decoder_layer_class, default_args, forward_bank, register_let_parameters
+    H, Tn = 1024, 256
+    cfg = S.make_config(None, family="llama", hidden_size=H, inter=2048, heads=8, kv_heads=8)
+    x = S.make_calib_inputs(2, Tn, H, dtype=torch.bfloat16).to(DEV)
+    mask = S.causal_mask(Tn).to(DEV)
+    pos = torch.arange(Tn, device=DEV)[None]
+    sc, sh = S.synth_act_stats(cfg, 1)
+    outs, calls = {}, {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OQ_INT_FPROP", flag)
+        args = default_args(wbits=4, abits=4, lwc=True, let=True, net="llama", nsamples=2)
+        q = decoder_layer_class("llama")(cfg, S.make_layer(cfg, seed=5, device=DEV), args).to(DEV)
+        q.compute_dtype = torch.bfloat16
+        q.set_quant_state(False, True)
+        q.let = True
+        register_let_parameters(q, "llama", sc, sh, 0.5, 0, DEV)
+        with torch.no_grad():
+            for p in q.parameters():
+                p.data = p.data.float()
+        q.smooth_and_quant_inplace()
+        n = {"i8": 0}
+        orig = ops.gemm_i8
+
+        def spy(*a, **k):
+            n["i8"] += 1
+            return orig(*a, **k)
+        monkeypatch.setattr(ops, "gemm_i8", spy)
+        out = torch.empty_like(x)
+        forward_bank(q, x, out, mask.float(), pos, True, chunk=2)
+        monkeypatch.setattr(ops, "gemm_i8", orig)
+        outs[flag], calls[flag] = out.float(), n["i8"]
+    assert calls["1"] == 7 and calls["0"] == 0, calls
+    # the oracle's fp32 forward with the same (initial) learnables folded in is the yardstick: the integer pass must be the closer
+    # one (elementwise both differ from it by whole 4-bit levels wherever a downstream rounding decision flips: compare in L2)
+    from oracle import ref_cpu as R
+    layer = S.make_layer(cfg, seed=5, device="cpu")
+    weights = {n_: p.detach().float() for n_, p in layer.named_parameters()}
+    cd = dict(hidden_size=H, num_attention_heads=8, num_key_value_heads=8, rms_norm_eps=1e-6)
+    blk = R.Block("llama", cd, weights, R.QuantSpec(4, 4, None, True, True), max_pos=Tn)
+    blk.register_let(sc, sh, 0.5, 0, "model.layers")
+    with torch.no_grad():
+        ref = blk.forward(x.float().cpu(), mask.float().cpu(), pos.cpu(), temps=blk.temporaries(), act_quant=True)
+    e_int = float((outs["1"].cpu() - ref).norm() / ref.norm())
+    e_bf = float((outs["0"].cpu() - ref).norm() / ref.norm())
+    print(f"propagate pass vs the fp32 oracle, relative L2: integer operands {e_int:.3e}, bf16 operands {e_bf:.3e}")
+    assert torch.isfinite(outs["1"]).all() and e_int < 6e-2 and e_int <= e_bf * 1.05, (e_int, e_bf)
