@@ -117,6 +117,32 @@ def test_block_step(fname):
         close(blk.forward(x, mask, pos, temps=None, act_quant=False), g["out_fp"], rtol=1e-5, atol=1e-5, what="fp")
 
 
+@pytest.mark.parametrize("fname", ["g3_step_llama_hd128_w4a4_lwc_let.npz", "g3_step_llama_w4a4_lwc_let.npz",
+                                   "g3_step_opt_w4a4_lwc_let.npz"])
+@pytest.mark.parametrize("int_fprop", [False, True])
+def test_storage_model_is_the_pinned_step_when_nothing_is_rounded(fname, int_fprop):
+    """The precision-mode emulation of oracle/ref_cpu.py (Block.forward(act_dtype=..., int_fprop=...), temporaries(store_dtype,
+    int_fprop)) is what the production-mode GPU tests are held against.  It must be the reference-pinned fp32 step in
+    everything but its rounding points: with float32 as the "storage" dtype every rounding is the identity, and the model
+    -- fused-attention branch, integer-fprop Linear (_IntFpropLinear), fused producer branches and all -- has to reproduce
+    the golden step: output, loss and every gradient, at the fixture's own tolerances."""
+    g, meta = load_golden(fname)
+    blk = _block_from_step(g, meta)
+    x, tgt, mask = T(g["x"]), T(g["target"]), T(g["mask"])
+    pos = torch.from_numpy(g["position_ids"])
+    temps = blk.temporaries(store_dtype=torch.float32, int_fprop=int_fprop)
+    out = blk.forward(x, mask, pos, temps=temps, act_quant=True, act_dtype=torch.float32, int_fprop=int_fprop)
+    # (the model's fused-attention branch evaluates the softmax as exp(s - max) / sum: fp32 op-order noise of a few 1e-5)
+    close(out.detach(), g["out"], rtol=1e-3, atol=1e-4, what="out")
+    loss = torch.nn.functional.mse_loss(tgt, out)
+    close(loss.detach().reshape(1), g["loss"].reshape(1), rtol=1e-5, what="loss")
+    loss.backward()
+    for n, p in blk.params.items():
+        ref = g["grad." + n]
+        scale = max(np.abs(ref).max(), 1e-12)
+        close(p.grad / scale, ref / scale, rtol=5e-3, atol=5e-5, what="grad " + n)
+
+
 TRAJ_FILES = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "g4_traj_*.npz")))
 
 
