@@ -204,7 +204,7 @@ def kernel_rooflines(runner, quant_inps, fp_inps, cfg, n_prof=3):
             if nb == 1 and (min(M, N, K) >= 1024 or M * N * K >= 2048 * H * H):
                 lin.append((dt, 2.0 * M * N * K))
         elif name == "oq_gemm_i8":
-            M, N, K = a[11], a[12], a[13]
+            M, N, K = a[13], a[14], a[15]
             allg += dt
             shapes.append(((M, N, K, 1, 1, 1, 0, "int8"), dt, 2.0 * M * N * K))
             lin8.append((dt, 2.0 * M * N * K))

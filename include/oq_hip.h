@@ -141,10 +141,13 @@ int oq_gemm_ws(const void* a, const void* bm, void* c, const float* bias, const 
  * a_codes [M][lda], b_codes [N][ldb]: int8, the grid codes as the quantiser entry points write them into their `codes`
  * output (plain codes; code - 128 on 8-bit grids); `*_csum[r]` = sum over k of the STORED codes of row r, as float.  The contraction runs on
  * v_mfma_i32_16x16x64_i8 into int32 (exact); scales, the three zero-point terms, bias and addend are applied in fp32 in the
- * epilogue.  out_dtype OQ_F32 / OQ_BF16; addend has the output's dtype and leading dimension.  Fast path: K % 128 == 0,
- * N % 8 == 0, N >= 128, 16-byte aligned rows; anything else runs a plain one-thread-per-output kernel (same arithmetic). */
-int oq_gemm_i8(const void* a_codes, const void* b_codes, void* c, const float* bias, const void* addend,
-               const float* a_scale, const float* a_zp, const float* a_csum,
+ * epilogue.  out_dtype OQ_F32 / OQ_BF16; addend (addend_dtype OQ_F32 / OQ_BF16, independent of the output's) has the
+ * output's leading dimension; c_wide (may be NULL): a second copy of the un-rounded fp32 result, same leading dimension --
+ * the hidden state's side channel in front of the next 4-bit rounding decision while c is its bf16 copy.  Fast path:
+ * K % 128 == 0, N % 8 == 0, N >= 128, 16-byte aligned rows; anything else runs a plain one-thread-per-output kernel (same
+ * arithmetic). */
+int oq_gemm_i8(const void* a_codes, const void* b_codes, void* c, float* c_wide, const float* bias, const void* addend,
+               int addend_dtype, const float* a_scale, const float* a_zp, const float* a_csum,
                const float* b_scale, const float* b_zp, const float* b_csum,
                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                int a_bits, int b_bits, int out_dtype, void* stream);
@@ -223,10 +226,13 @@ int oq_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64_t T, int n
  * heads are not (models/int_llama_layer.py:124-125); the quantised tensors / their gradients stay three contiguous
  * [rows, nh_i, 128] buffers as the attention kernels expect.  scale / zp / xmin / xmax: [rows * (nhq + nhk + nhv)].
  * nbits == 16 (these two entry points only) is the identity grid of quantize/quantizer.py:109-110: rotate and split only
- * (weight-only configurations run q | k | v as one stacked GEMM too); scale / zp / xmin / xmax may then be NULL. */
+ * (weight-only configurations run q | k | v as one stacked GEMM too); scale / zp / xmin / xmax may then be NULL.
+ * out_grid != 0 (nbits <= 8): yq / yk / yv receive the GRID COORDINATES clamp(round(x / s) + z, 0, 2^nbits - 1) - z of
+ * quantize/quantizer.py:93-100 -- small integers, exact in bf16 -- instead of the values coordinate * s; together with
+ * `scale` they are the operands of oq_attn_fwd_grid / oq_attn_bwd_grid. */
 int oq_qkv_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nhq, int nhk, int nhv, int hd,
                           const float* cos, const float* sin, int nbits, void* yq, void* yk, void* yv, int y_dtype,
-                          float* scale, float* zp, float* xmin, float* xmax, void* stream);
+                          int out_grid, float* scale, float* zp, float* xmin, float* xmax, void* stream);
 int oq_qkv_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nhq, int nhk, int nhv, int hd,
                           const float* cos, const float* sin, int nbits, const float* xmin, const float* xmax,
                           const void* gq, const void* gk, const void* gv, int g_dtype, void* gx, void* stream);
@@ -283,11 +289,28 @@ int oq_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
 int oq_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* go, const float* lse,
                 float* dsum, void* ds_t, void* gk, void* gv, int dtype, int64_t bs, int64_t T, int nh, int nkv, int hd,
                 float scale, int causal, void* stream);
+/* The same attention (models/int_llama_layer.py:140-163) on the head quantisers' INTEGER GRID: nq / nk / nv (bf16) hold the
+ * grid coordinates code - zero_point of quant_x1 / quant_x2 (oq_qkv_rope_quant_fwd with out_grid), sq / sk / sv the
+ * per-(token, head) scales, element [(b*T + t) * ld_s + head] (three offsets into the one [rows, nhq + nhk + nhv] vector
+ * that call writes).  The fake-quantised values of quantize/quantizer.py:100 are coordinate * scale; here the products
+ * Q K^T and P V contract the coordinates -- exactly, small integers accumulated in f32 -- and the scales are applied in f32
+ * to the score / probability, so that q, k, v are never rounded to 16 bits; the probabilities meet the V coordinates as a
+ * bf16 high + low pair (two MFMAs).  o (bf16) and, when o32 != NULL, the same result in f32 are written.  The backward
+ * returns gk, gv and (through ds_t and one oq_gemm against the K COORDINATES) dQ as gradients with respect to the
+ * fake-quantised VALUES, exactly as oq_attn_bwd does; with o32 (the forward's f32 output) D = rowsum(dO * O) is taken from it. */
+int oq_attn_fwd_grid(const void* nq, const void* nk, const void* nv, const float* sq, const float* sk, const float* sv,
+                     int64_t ld_s, void* o, float* o32, float* lse, int64_t bs, int64_t T, int nh, int nkv, int hd,
+                     float scale, int causal, void* stream);
+int oq_attn_bwd_grid(const void* nq, const void* nk, const void* nv, const float* sq, const float* sk, const float* sv,
+                     int64_t ld_s, const void* o, const float* o32, const void* go, const float* lse, float* dsum, void* ds_t,
+                     void* gk, void* gv, int64_t bs, int64_t T, int nh, int nkv, int hd, float scale, int causal, void* stream);
 /* loss[0] = mean((out-t1)^2) (+ mean((out-t2)^2) if t2); g = dloss/dout * gscale.  `loss` is a buffer of
  * 1 + OQ_MSE_MAX_BLOCKS floats: loss[0] receives the result, loss[1..] is scratch for the per-workgroup partial sums
  * that a second tiny kernel adds in a fixed order (no atomics: the reported loss is bit-reproducible). */
 #define OQ_MSE_MAX_BLOCKS 1024
-int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, int dtype, int64_t n, float gscale,
+/* out_dtype: dtype of `out` -- the targets' (`dtype`), or OQ_F32 next to bf16 targets / gradient (the block's output arriving
+ * through its un-rounded side channel, see oq_gemm_i8's c_wide). */
+int oq_mse_fwd_bwd(const void* out, int out_dtype, const void* t1, const void* t2, int dtype, int64_t n, float gscale,
                    float* loss, void* g, void* stream);
 /* y = a + b (residual) and y = a * s (OPT query scaling) */
 int oq_add(const void* a, const void* b, void* y, int dtype, int64_t n, void* stream);

@@ -26,7 +26,7 @@ SIGNATURES = {
                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp],
     "oq_gemm_ws": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _vp],
-    "oq_gemm_i8": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
+    "oq_gemm_i8": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
     "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp],
     "oq_norm_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "oq_norm_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
@@ -39,7 +39,8 @@ SIGNATURES = {
     "oq_norm_quant_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
     "oq_rope_quant_fwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
     "oq_rope_quant_bwd": [_vp, _i32, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
-    "oq_qkv_rope_quant_fwd": [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp],
+    "oq_qkv_rope_quant_fwd": [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp,
+                              _vp],
     "oq_qkv_rope_quant_bwd": [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp],
     "oq_silu_mul_quant_fwd": [_vp, _vp, _i32, _i64, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "oq_silu_mul_quant_bwd": [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp],
@@ -50,7 +51,10 @@ SIGNATURES = {
     "oq_softmax_bwd": [_vp, _vp, _vp, _i32, _i64, _i64, _f32, _i32, _vp],
     "oq_attn_fwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
     "oq_attn_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
-    "oq_mse_fwd_bwd": [_vp, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],
+    "oq_attn_fwd_grid": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp],
+    "oq_attn_bwd_grid": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32,
+                         _i32, _vp],
+    "oq_mse_fwd_bwd": [_vp, _i32, _vp, _vp, _i32, _i64, _f32, _vp, _vp, _vp],
     "oq_add": [_vp, _vp, _vp, _i32, _i64, _vp],
     "oq_scale": [_vp, _f32, _vp, _i32, _i64, _vp],
     "oq_copy_samples": [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp],

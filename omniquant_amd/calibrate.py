@@ -131,7 +131,10 @@ class StepRunner:
         self.qlayer.smooth_and_quant_temporary()
         out = self._forward()
         g = torch.empty_like(out)
-        C.call("oq_mse_fwd_bwd", C.ptr(out), C.ptr(self.t1), C.ptr(self.t2), C.dt(out), out.numel(), 1.0,
+        from . import ops
+        wide = ops.wide_of(out) if out.dtype == torch.bfloat16 else None      # the block output's un-rounded side channel
+        src = wide.contiguous() if wide is not None else out
+        C.call("oq_mse_fwd_bwd", C.ptr(src), C.dt(src), C.ptr(self.t1), C.ptr(self.t2), C.dt(out), out.numel(), 1.0,
                C.fptr(self._loss_buf), C.ptr(g), C.stream())
         self.opt.zero_grad(lazy=True)       # a no-op once the fused optimiser step clears the arena behind each update
         out.backward(g)

@@ -42,6 +42,11 @@ struct AttnP {
     int64_t T;
     int nh, nkv;
     float scale, scale_log2;
+    // grid mode (oq_attn_*_grid): q / k / v hold the quantisers' integer grid coordinates (code - zero_point, exact in bf16);
+    // value = coordinate * s?[(b*T + t) * lds + head]
+    const float *sq, *sk, *sv;
+    int64_t lds;
+    float* o32;            // optional second copy of O in f32 (grid forward)
 };
 
 // s(row): built for the DOCUMENTED lane groups of the two read instructions (MI355X_MICROARCH.md, LDS table):
@@ -113,9 +118,13 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // reproducible.  `tools/debug_attn_det.py` checks bitwise reproducibility; the tests do as well.
 // One key/value tile for one wave.  DIAG: the tile crosses the diagonal of this wave's queries (mask needed).
 // dq = (query index of lane's column) - (first key of the tile) - 4*(lane>>4): key 16kb+i is masked iff 16kb+i > dq.
-template <bool DIAG>
+// GRID: the operands are integer grid coordinates; the S^T block is scaled by sk[key] (ksc[0..63]) here and by
+// c2q[qb] = scale * log2e * sq[query] in the exponent, the probabilities by sv[key] (ksc[64..127]) and split into a bf16 high
+// and low part (two MFMAs per block: 16 mantissa bits instead of 8 in front of the exact integer V operand).
+template <bool DIAG, bool GRID>
 __device__ __forceinline__ void fwd_tile(const char* Ks, const char* Vs, const bf16x8 (&qf)[2][4], f32x4 (&o)[2][8],
-                                         float (&m)[2], float (&l)[2], const int (&dq)[2], float c2, int lane) {
+                                         float (&m)[2], float (&l)[2], const int (&dq)[2], const float (&c2q)[2],
+                                         const float* ksc, int lane) {
     f32x4 st[4][2];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -135,8 +144,20 @@ __device__ __forceinline__ void fwd_tile(const char* Ks, const char* Vs, const b
     }
     bf16x8 vf[2];
     vf[0] = frag_tr(Vs, 0, 0, lane);             // in flight under the softmax arithmetic
+    if (GRID) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const f32x4 skk = *reinterpret_cast<const f32x4*>(ksc + 16 * kb + 4 * (lane >> 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                st[kb][0][i] *= skk[i];
+                st[kb][1][i] *= skk[i];
+            }
+        }
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
+        const float c2 = c2q[qb];
         float mx = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
@@ -167,22 +188,51 @@ __device__ __forceinline__ void fwd_tile(const char* Ks, const char* Vs, const b
                 for (int i = 0; i < 4; ++i) o[qb][db][i] *= alpha;
         }
     }
+    if (GRID) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const f32x4 svk = *reinterpret_cast<const f32x4*>(ksc + 64 + 16 * kb + 4 * (lane >> 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                st[kb][0][i] *= svk[i];
+                st[kb][1][i] *= svk[i];
+            }
+        }
+    }
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
         const bf16x8 p0 = pack8(st[2 * kc][0], st[2 * kc + 1][0]);
         const bf16x8 p1 = pack8(st[2 * kc][1], st[2 * kc + 1][1]);
+        bf16x8 r0, r1;
+        if (GRID) {                 // low parts: what the bf16 rounding of the high parts dropped
+            f32x4 e[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    e[h][0][i] = st[2 * kc + h][0][i] - (float)p0[4 * h + i];
+                    e[h][1][i] = st[2 * kc + h][1][i] - (float)p1[4 * h + i];
+                }
+            r0 = pack8(e[0][0], e[1][0]);
+            r1 = pack8(e[0][1], e[1][1]);
+        }
 #pragma unroll
         for (int db = 0; db < 8; ++db) {
             const int nx = kc * 8 + db + 1;
             if (nx < 16) vf[nx & 1] = frag_tr(Vs, 32 * (nx >> 3), 16 * (nx & 7), lane);   // V^T: row = d 16db+(lane&15)
             o[0][db] = MFMA(vf[(nx - 1) & 1], p0, o[0][db]);        // O^T block: row = d 16db+4g+i, col = query
             o[1][db] = MFMA(vf[(nx - 1) & 1], p1, o[1][db]);
+            if (GRID) {
+                o[0][db] = MFMA(vf[(nx - 1) & 1], r0, o[0][db]);
+                o[1][db] = MFMA(vf[(nx - 1) & 1], r1, o[1][db]);
+            }
         }
     }
 }
 
+template <bool GRID>
 __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p, int nqt, int nhb) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];   // [stage][K | V]
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE + 2 * 128 * 4];   // [stage][K | V], [stage][sk | sv] (grid mode)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     // Work placement (speed only): items sorted heaviest-first (rank r: qt = nqt-1 - r/nhb) are dealt round-robin to
     // the 8 XCDs (id % 8), and inside an XCD the second half of the local sequence is reversed, so the two
@@ -219,11 +269,24 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p, int nqt, int 
         for (int db = 0; db < 8; ++db) o[qb][db] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int ntiles = 2 * qt + 2;
+    float* kscs = reinterpret_cast<float*>(smem + 4 * TILE);
+    // grid mode: per-key scales of the tile (threads 0-63: sk, 64-127: sv); per-query exponent factors
+    const float* kscp = nullptr;
+    float c2q[2] = {p.scale_log2, p.scale_log2};
+    if (GRID) {
+        kscp = (tid < 64 ? p.sk : p.sv) + ((int64_t)b * p.T) * p.lds + hk;
+        const float* sqp = p.sq + ((int64_t)b * p.T) * p.lds + h;
+        c2q[0] *= sqp[(int64_t)(qw0 + c) * p.lds];
+        c2q[1] *= sqp[(int64_t)(qw0 + 16 + c) * p.lds];
+    }
+    float rsc = 0.f;
     u32x4 rk[4], rv[4];
     tile_gload(kp, ldk, tid, rk);
     tile_gload(vp, ldk, tid, rv);
+    if (GRID && tid < 128) rsc = kscp[(int64_t)(tid & 63) * p.lds];
     tile_sstore(smem, tid, rk);
     tile_sstore(smem + TILE, tid, rv);
+    if (GRID && tid < 128) kscs[tid] = rsc;
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing (q fragments included) is pending at loop entry
     __syncthreads();
     for (int j = 0; j < ntiles; ++j) {
@@ -231,18 +294,20 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p, int nqt, int 
         if (j + 1 < ntiles) {
             tile_gload(kp + (int64_t)(64 * (j + 1)) * ldk, ldk, tid, rk);
             tile_gload(vp + (int64_t)(64 * (j + 1)) * ldk, ldk, tid, rv);
+            if (GRID && tid < 128) rsc = kscp[(int64_t)(64 * (j + 1) + (tid & 63)) * p.lds];
         }
         const char* Ks = smem + cur * 2 * TILE;
         const char* Vs = Ks + TILE;
         const int kpos0 = 64 * j;
         if (kpos0 <= qw0 + 31) {     // wave-uniform: this wave has at least one unmasked (query, key) pair in the tile
             const int dq[2] = {qw0 + c - kpos0 - 4 * g, qw0 + 16 + c - kpos0 - 4 * g};
-            if (kpos0 + 63 > qw0) fwd_tile<true>(Ks, Vs, qf, o, m, l, dq, p.scale_log2, lane);
-            else fwd_tile<false>(Ks, Vs, qf, o, m, l, dq, p.scale_log2, lane);
+            if (kpos0 + 63 > qw0) fwd_tile<true, GRID>(Ks, Vs, qf, o, m, l, dq, c2q, kscs + cur * 128, lane);
+            else fwd_tile<false, GRID>(Ks, Vs, qf, o, m, l, dq, c2q, kscs + cur * 128, lane);
         }
         if (j + 1 < ntiles) {
             tile_sstore(smem + (cur ^ 1) * 2 * TILE, tid, rk);
             tile_sstore(smem + (cur ^ 1) * 2 * TILE + TILE, tid, rv);
+            if (GRID && tid < 128) kscs[(cur ^ 1) * 128 + tid] = rsc;
         }
         __syncthreads();
     }
@@ -261,6 +326,10 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p, int nqt, int 
 #pragma unroll
             for (int i = 0; i < 4; ++i) ov[i] = (bf16_t)(o[qb][db][i] * inv);
             *reinterpret_cast<bf4*>(op + (int64_t)qi * ldq + 16 * db + 4 * g) = ov;
+            if (GRID && p.o32) {
+                const f32x4 of = {o[qb][db][0] * inv, o[qb][db][1] * inv, o[qb][db][2] * inv, o[qb][db][3] * inv};
+                *reinterpret_cast<f32x4*>(p.o32 + ((int64_t)b * p.T + qi) * ldq + (int64_t)h * HD + 16 * db + 4 * g) = of;
+            }
         }
         if (g == 0) p.lse[((int64_t)b * p.nh + h) * p.T + qi] = m[qb] + __builtin_amdgcn_logf(ls);   // v_log_f32 = log2
     }
@@ -269,12 +338,14 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p, int nqt, int 
 // ---------------------------------------------------------------------------------------------------
 // D[b,h,q] = sum_d O[q,h,d] * dO[q,h,d]   (one 16-lane group per (q,h) row of 128)
 // ---------------------------------------------------------------------------------------------------
+template <typename TO>        // TO: float = the un-rounded output of the grid forward (p.o32), else its bf16 copy
 __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(AttnP p, int64_t nrows) {
     const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);    // row index over [bs*T*nh]
     if (r >= nrows) return;
     const int c = threadIdx.x & 15;
     float a[8], bq[8];
-    Vec8<bf16_t>::load(p.o + r * HD + c * 8, a);
+    if (sizeof(TO) == 4) Vec8<float>::load(p.o32 + r * HD + c * 8, a);
+    else Vec8<bf16_t>::load(p.o + r * HD + c * 8, a);
     Vec8<bf16_t>::load(p.go + r * HD + c * 8, bq);
     float s = 0.f;
 #pragma unroll
@@ -293,10 +364,15 @@ __global__ void __launch_bounds__(256) attn_bwd_prep_kernel(AttnP p, int64_t nro
 // ---------------------------------------------------------------------------------------------------
 // One 64-query tile for one wave (16 keys).  DIAG: the diagonal tile; query 16qb+4g+i is masked iff 16qb+i < mk
 // (mk = key - first query of the tile - 4g, per lane).
-template <bool DIAG>
+// GRID: q / k / v are grid coordinates.  c2 then carries scale*log2e*sk[key] and `scale` carries scale (both per lane: the
+// lane's column is its key), skk = sk[key], svk = sv[key], sq_s = the tile's 64 query scales: the score is s*sq[query]*c2,
+// dP = dp*svk, the stored dS^T (operand of the dQ GEMM against the K coordinates) is scaled by sk[key] and the dK operand
+// by sq[query].
+template <bool DIAG, bool GRID>
 __device__ __forceinline__ void bwd_phase1(const char* Qs, const char* Gs, const float* lse_s, const float* d_s,
                                            const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], bf16x8 (&pf)[2], bf16x8 (&sf)[2],
-                                           bf16_t* dst_row, int mk, float c2, float scale, int lane) {
+                                           bf16_t* dst_row, int mk, float c2, float scale, float skk, float svk,
+                                           const float* sq_s, int lane) {
     typedef __attribute__((ext_vector_type(4))) __bf16 bf4;
     const int g = lane >> 4;
     f32x4 pprev = {0.f, 0.f, 0.f, 0.f}, sprev = {0.f, 0.f, 0.f, 0.f};
@@ -315,18 +391,23 @@ __device__ __forceinline__ void bwd_phase1(const char* Qs, const char* Gs, const
             s = MFMA(qa[ks], kf[ks], s);        // row = query 16qb+4g+i, col = key
             dp = MFMA(ga[ks], vf[ks], dp);
         }
-        f32x4 pv, sv;
+        f32x4 pv, sv, q4 = {1.f, 1.f, 1.f, 1.f};
+        if (GRID) q4 = *reinterpret_cast<const f32x4*>(sq_s + 16 * qb + 4 * g);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float e = __builtin_amdgcn_exp2f(fmaf(s[i], c2, -l4[i]));
+            float e = __builtin_amdgcn_exp2f(fmaf(GRID ? s[i] * q4[i] : s[i], c2, -l4[i]));
             if (DIAG && 16 * qb + i < mk) e = 0.f;
             pv[i] = e;
-            sv[i] = e * (dp[i] - d4[i]) * scale;
+            sv[i] = e * ((GRID ? dp[i] * svk : dp[i]) - d4[i]) * scale;
         }
         bf4 dsv;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dsv[i] = (bf16_t)sv[i];
+        for (int i = 0; i < 4; ++i) dsv[i] = (bf16_t)(GRID ? sv[i] * skk : sv[i]);
         *reinterpret_cast<bf4*>(dst_row + 16 * qb) = dsv;           // dS^T[key][query 16qb+4g .. +4]
+        if (GRID) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] *= q4[i];
+        }
         if (qb & 1) {
             pf[qb >> 1] = pack8(pprev, pv);                        // B operand: k-slot = query, col = key
             sf[qb >> 1] = pack8(sprev, sv);
@@ -355,8 +436,9 @@ __device__ __forceinline__ void bwd_phase2(const char* Qs, const char* Gs, const
     }
 }
 
+template <bool GRID>
 __global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnP p, int nhb) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE + 2 * 2 * 64 * 4];   // [stage][Q | dO], [stage][lse | D]
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE + 2 * 3 * 64 * 4];   // [stage][Q | dO], [stage][lse | D | sq]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, g = lane >> 4, c = lane & 15;
     // heaviest key tiles (kvt = 0: all query tiles) first; consecutive ids = different heads of the same key tile, so
     // the round-robin id -> XCD placement gives every XCD the same mix
@@ -399,15 +481,28 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnP p, int nhb) {
     }
     u32x4 rq[4];
     float rs = 0.f;
+    // grid mode: per-lane key scales, per-tile query scales (threads 128-191 stage them next to lse / D)
+    float c2 = p.scale_log2, skk = 1.f, svk = 1.f;
+    const float* sqp = nullptr;
+    if (GRID) {
+        skk = p.sk[((int64_t)b * p.T + kw0 + c) * p.lds + hk];
+        svk = p.sv[((int64_t)b * p.T + kw0 + c) * p.lds + hk];
+        c2 *= skk;
+        sqp = p.sq + ((int64_t)b * p.T) * p.lds + h;
+    }
+    const int nstat = GRID ? 192 : 128;
+    auto stat_load = [&](int64_t q0) {
+        return tid < 64 ? lsep[q0 + tid] : tid < 128 ? dsp[q0 + tid - 64] : sqp[(q0 + tid - 128) * p.lds];
+    };
     {
         u32x4 rg[4];
         const int64_t q0 = (int64_t)kvt * 64;
         tile_gload(qp + q0 * ldq, ldq, tid, rq);
         tile_gload(gop + q0 * ldq, ldq, tid, rg);
-        if (tid < 128) rs = tid < 64 ? lsep[q0 + tid] : dsp[q0 + tid - 64];
+        if (tid < nstat) rs = stat_load(q0);
         tile_sstore(smem, tid, rq);
         tile_sstore(smem + TILE, tid, rg);
-        if (tid < 128) stat[tid] = rs;
+        if (tid < nstat) stat[tid] = rs;
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): k/v fragments and the zero-fill stores are done
     __syncthreads();
@@ -418,20 +513,21 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnP p, int nhb) {
         const int64_t q1 = (int64_t)(qt + 1) * 64;
         if (more) {            // staging in two halves (Q under phase 1, dO under phase 2): 16 registers instead of 32
             tile_gload(qp + q1 * ldq, ldq, tid, rq);
-            if (tid < 128) rs = tid < 64 ? lsep[q1 + tid] : dsp[q1 + tid - 64];
+            if (tid < nstat) rs = stat_load(q1);
         }
         const char* Qs = smem + cur * 2 * TILE;
         const char* Gs = Qs + TILE;
-        const float* lse_s = stat + cur * 128;
+        const float* lse_s = stat + cur * 192;
         bf16x8 pf[2], sf[2];
         if (qt == kvt)
-            bwd_phase1<true>(Qs, Gs, lse_s, lse_s + 64, kf, vf, pf, sf, dst_row + qt * 64, 16 * w + c - 4 * g,
-                             p.scale_log2, p.scale, lane);
+            bwd_phase1<true, GRID>(Qs, Gs, lse_s, lse_s + 64, kf, vf, pf, sf, dst_row + qt * 64, 16 * w + c - 4 * g,
+                                   c2, p.scale, skk, svk, lse_s + 128, lane);
         else
-            bwd_phase1<false>(Qs, Gs, lse_s, lse_s + 64, kf, vf, pf, sf, dst_row + qt * 64, 0, p.scale_log2, p.scale, lane);
+            bwd_phase1<false, GRID>(Qs, Gs, lse_s, lse_s + 64, kf, vf, pf, sf, dst_row + qt * 64, 0, c2, p.scale, skk, svk,
+                                    lse_s + 128, lane);
         if (more) {
             tile_sstore(smem + (cur ^ 1) * 2 * TILE, tid, rq);
-            if (tid < 128) stat[(cur ^ 1) * 128 + tid] = rs;
+            if (tid < nstat) stat[(cur ^ 1) * 192 + tid] = rs;
             tile_gload(gop + q1 * ldq, ldq, tid, rq);
         }
         bwd_phase2(Qs, Gs, pf, sf, dk, dv, lane);
@@ -477,9 +573,29 @@ extern "C" int oq_attn_fwd(const void* q, const void* k, const void* v, void* o,
     p.T = T; p.nh = nh; p.nkv = nkv; p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
     const int nqt = (int)(T / 128);
     OQ_CHECK_ARG((int64_t)nqt * nh * bs < (1ll << 30), "oq_attn_fwd: too many workgroups");
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(nqt * nh * bs)), dim3(256), 0, (hipStream_t)stream, p, nqt,
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)(nqt * nh * bs)), dim3(256), 0, (hipStream_t)stream, p, nqt,
                        (int)(nh * bs));
     OQ_CHECK_LAUNCH("oq_attn_fwd");
+    return OQ_OK;
+}
+
+extern "C" int oq_attn_fwd_grid(const void* nq, const void* nk, const void* nv, const float* sq, const float* sk,
+                                const float* sv, int64_t ld_s, void* o, float* o32, float* lse, int64_t bs, int64_t T, int nh,
+                                int nkv, int hd, float scale, int causal, void* stream) {
+    OQ_CHECK_ARG(nq && nk && nv && sq && sk && sv && o && lse, "oq_attn_fwd_grid: null pointer");
+    if (int rc = check_common("oq_attn_fwd_grid", OQ_BF16, bs, T, nh, nkv, hd, causal)) return rc;
+    OQ_CHECK_ARG(ld_s >= nh, "oq_attn_fwd_grid: scale row stride %lld < %d heads", (long long)ld_s, nh);
+    OQ_CHECK_ARG(oq_aligned16(nq) && oq_aligned16(nk) && oq_aligned16(nv) && oq_aligned16(o) && oq_aligned16(o32),
+                 "oq_attn_fwd_grid: 16-B alignment");
+    AttnP p{};
+    p.q = (const bf16_t*)nq; p.k = (const bf16_t*)nk; p.v = (const bf16_t*)nv; p.o = (bf16_t*)o; p.o32 = o32; p.lse = lse;
+    p.sq = sq; p.sk = sk; p.sv = sv; p.lds = ld_s;
+    p.T = T; p.nh = nh; p.nkv = nkv; p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+    const int nqt = (int)(T / 128);
+    OQ_CHECK_ARG((int64_t)nqt * nh * bs < (1ll << 30), "oq_attn_fwd_grid: too many workgroups");
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)(nqt * nh * bs)), dim3(256), 0, (hipStream_t)stream, p, nqt,
+                       (int)(nh * bs));
+    OQ_CHECK_LAUNCH("oq_attn_fwd_grid");
     return OQ_OK;
 }
 
@@ -497,11 +613,42 @@ extern "C" int oq_attn_bwd(const void* q, const void* k, const void* v, const vo
     p.gk = (bf16_t*)gk; p.gv = (bf16_t*)gv;
     p.T = T; p.nh = nh; p.nkv = nkv; p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
     const int64_t nrows = bs * T * nh;
-    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, p,
+    hipLaunchKernelGGL(attn_bwd_prep_kernel<bf16_t>, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, p,
                        nrows);
     OQ_CHECK_ARG((T / 64) * nh * bs < (1ll << 30), "oq_attn_bwd: too many workgroups");
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((T / 64) * nh * bs)), dim3(256), 0, (hipStream_t)stream, p,
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3((unsigned)((T / 64) * nh * bs)), dim3(256), 0, (hipStream_t)stream, p,
                        (int)(nh * bs));
     OQ_CHECK_LAUNCH("oq_attn_bwd");
+    return OQ_OK;
+}
+
+extern "C" int oq_attn_bwd_grid(const void* nq, const void* nk, const void* nv, const float* sq, const float* sk,
+                                const float* sv, int64_t ld_s, const void* o, const float* o32, const void* go, const float* lse,
+                                float* dsum, void* ds_t, void* gk, void* gv, int64_t bs, int64_t T, int nh, int nkv, int hd,
+                                float scale, int causal, void* stream) {
+    OQ_CHECK_ARG(nq && nk && nv && sq && sk && sv && o && go && lse && dsum && ds_t && gk && gv, "oq_attn_bwd_grid: null pointer");
+    if (int rc = check_common("oq_attn_bwd_grid", OQ_BF16, bs, T, nh, nkv, hd, causal)) return rc;
+    OQ_CHECK_ARG(ld_s >= nh, "oq_attn_bwd_grid: scale row stride %lld < %d heads", (long long)ld_s, nh);
+    OQ_CHECK_ARG(oq_aligned16(nq) && oq_aligned16(nk) && oq_aligned16(nv) && oq_aligned16(o) && oq_aligned16(go) &&
+                     oq_aligned16(ds_t) && oq_aligned16(gk) && oq_aligned16(gv) && oq_aligned16(lse) && oq_aligned16(dsum) &&
+                     oq_aligned16(o32),
+                 "oq_attn_bwd_grid: 16-B alignment");
+    AttnP p{};
+    p.q = (const bf16_t*)nq; p.k = (const bf16_t*)nk; p.v = (const bf16_t*)nv; p.o = (bf16_t*)const_cast<void*>(o);
+    p.go = (const bf16_t*)go; p.lse = const_cast<float*>(lse); p.dsum = dsum; p.dst = (bf16_t*)ds_t;
+    p.gk = (bf16_t*)gk; p.gv = (bf16_t*)gv;
+    p.sq = sq; p.sk = sk; p.sv = sv; p.lds = ld_s; p.o32 = const_cast<float*>(o32);
+    p.T = T; p.nh = nh; p.nkv = nkv; p.scale = scale; p.scale_log2 = scale * 1.4426950408889634f;
+    const int64_t nrows = bs * T * nh;
+    if (o32)
+        hipLaunchKernelGGL(attn_bwd_prep_kernel<float>, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, p,
+                           nrows);
+    else
+        hipLaunchKernelGGL(attn_bwd_prep_kernel<bf16_t>, dim3((unsigned)((nrows + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                           p, nrows);
+    OQ_CHECK_ARG((T / 64) * nh * bs < (1ll << 30), "oq_attn_bwd_grid: too many workgroups");
+    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3((unsigned)((T / 64) * nh * bs)), dim3(256), 0, (hipStream_t)stream, p,
+                       (int)(nh * bs));
+    OQ_CHECK_LAUNCH("oq_attn_bwd_grid");
     return OQ_OK;
 }

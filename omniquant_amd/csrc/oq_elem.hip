@@ -242,8 +242,9 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const T* p, const T* g
 }
 
 // ---- MSE loss + gradient -------------------------------------------------------------------------------
-template <typename T>
-__global__ void __launch_bounds__(256) mse_kernel(const T* out, const T* t1, const T* t2, int64_t n, float gscale,
+// TO: dtype of `out` (float32 when the block's output arrives through its un-rounded side channel)
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256) mse_kernel(const TO* out, const T* t1, const T* t2, int64_t n, float gscale,
                                                   float* part, T* g) {
     __shared__ float red[4];
     const int64_t nvec = n / 8;
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(256) mse_kernel(const T* out, const T* t1, con
     float acc = 0.f;
     for (int64_t v = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
         float o[8], a[8], b[8], gg[8];
-        Vec8<T>::load(out + v * 8, o);
+        Vec8<TO>::load(out + v * 8, o);
         Vec8<T>::load(t1 + v * 8, a);
         if (t2) Vec8<T>::load(t2 + v * 8, b);
 #pragma unroll
@@ -594,18 +595,20 @@ extern "C" int oq_softmax_bwd(const void* p, const void* gp, void* gs, int dtype
               hipLaunchKernelGGL((softmax_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)p, (const bf16_t*)gp, (bf16_t*)gs, rows, cols, alpha, causal));
 }
 
-extern "C" int oq_mse_fwd_bwd(const void* out, const void* t1, const void* t2, int dtype, int64_t n, float gscale,
+extern "C" int oq_mse_fwd_bwd(const void* out, int out_dtype, const void* t1, const void* t2, int dtype, int64_t n, float gscale,
                               float* loss, void* g, void* stream) {
     EW_CHECK("oq_mse_fwd_bwd", n);
     OQ_CHECK_ARG(out && t1 && loss && g, "oq_mse_fwd_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const int64_t grid = ew_grid(n / 8) > OQ_MSE_MAX_BLOCKS ? OQ_MSE_MAX_BLOCKS : ew_grid(n / 8);
-    if (dtype == OQ_F32)
-        hipLaunchKernelGGL((mse_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)out, (const float*)t1, (const float*)t2, n, gscale, loss + 1, (float*)g);
-    else if (dtype == OQ_BF16)
-        hipLaunchKernelGGL((mse_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)t1, (const bf16_t*)t2, n, gscale, loss + 1, (bf16_t*)g);
+    if (dtype == OQ_F32 && out_dtype == OQ_F32)
+        hipLaunchKernelGGL((mse_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)out, (const float*)t1, (const float*)t2, n, gscale, loss + 1, (float*)g);
+    else if (dtype == OQ_BF16 && out_dtype == OQ_BF16)
+        hipLaunchKernelGGL((mse_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)t1, (const bf16_t*)t2, n, gscale, loss + 1, (bf16_t*)g);
+    else if (dtype == OQ_BF16 && out_dtype == OQ_F32)
+        hipLaunchKernelGGL((mse_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const float*)out, (const bf16_t*)t1, (const bf16_t*)t2, n, gscale, loss + 1, (bf16_t*)g);
     else {
-        oq_set_error("oq_mse_fwd_bwd: dtype %d unsupported", dtype);
+        oq_set_error("oq_mse_fwd_bwd: dtypes %d (out %d) unsupported", dtype, out_dtype);
         return OQ_E_UNSUPPORTED;
     }
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(64), 0, st, loss + 1, (int)grid, loss);

@@ -31,6 +31,8 @@ struct GemmI8P {
     void* c;
     const float* bias;
     const void* addend;
+    int add_f32;                    // addend is float32 (else bf16)
+    float* cw32;                    // optional second copy of the result in float32 (same ldc)
     const float *sa, *za, *ca;      // per output row t: scale, rounded zero-point, sum of the stored codes of the row
     const float *sw, *zw, *cw;      // per output column n (= weight row)
     int64_t M, N, K, lda, ldb, ldc;
@@ -242,13 +244,14 @@ __global__ void __launch_bounds__(512) gemm_i8_p3_kernel(GemmI8P p) {
         }
         TOUT* dst = C + m * p.ldc + n;
         if (p.addend) {
-            const TOUT* ad = reinterpret_cast<const TOUT*>(p.addend) + m * p.ldc + n;
             float a8[8];
-            Vec8<TOUT>::load(ad, a8);
+            if (p.add_f32) Vec8<float>::load(reinterpret_cast<const float*>(p.addend) + m * p.ldc + n, a8);
+            else Vec8<bf16_t>::load(reinterpret_cast<const bf16_t*>(p.addend) + m * p.ldc + n, a8);
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] += a8[r];
         }
         Vec8<TOUT>::store(dst, v);
+        if (p.cw32) Vec8<float>::store(p.cw32 + m * p.ldc + n, v);
     }
 }
 
@@ -268,8 +271,11 @@ __global__ void __launch_bounds__(256) gemm_i8_ref_kernel(GemmI8P p) {
     inner = fmaf(-z_w, a2, inner);
     float v = fmaf(p.sa[m] * p.sw[n], inner, p.bias ? p.bias[n] : 0.f);
     TOUT* C = reinterpret_cast<TOUT*>(p.c);
-    if (p.addend) v += (float)reinterpret_cast<const TOUT*>(p.addend)[m * p.ldc + n];
+    if (p.addend)
+        v += p.add_f32 ? reinterpret_cast<const float*>(p.addend)[m * p.ldc + n]
+                       : (float)reinterpret_cast<const bf16_t*>(p.addend)[m * p.ldc + n];
     C[m * p.ldc + n] = (TOUT)v;
+    if (p.cw32) p.cw32[m * p.ldc + n] = v;
 }
 
 int dbg_env_i8(const char* name, int dflt) {
@@ -279,26 +285,28 @@ int dbg_env_i8(const char* name, int dflt) {
 
 }  // namespace
 
-extern "C" int oq_gemm_i8(const void* a_codes, const void* b_codes, void* c, const float* bias, const void* addend,
-                          const float* a_scale, const float* a_zp, const float* a_csum, const float* b_scale, const float* b_zp,
+extern "C" int oq_gemm_i8(const void* a_codes, const void* b_codes, void* c, float* c_wide, const float* bias,
+                          const void* addend, int addend_dtype, const float* a_scale, const float* a_zp, const float* a_csum, const float* b_scale, const float* b_zp,
                           const float* b_csum, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                           int a_bits, int b_bits, int out_dtype, void* stream) {
     OQ_CHECK_ARG(a_codes && b_codes && c && a_scale && a_zp && a_csum && b_scale && b_zp && b_csum, "oq_gemm_i8: null operand");
     OQ_CHECK_ARG(M > 0 && N > 0 && K > 0, "oq_gemm_i8: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     OQ_CHECK_ARG(out_dtype == OQ_F32 || out_dtype == OQ_BF16, "oq_gemm_i8: out dtype %d", out_dtype);
+    OQ_CHECK_ARG(!addend || addend_dtype == OQ_F32 || addend_dtype == OQ_BF16, "oq_gemm_i8: addend dtype %d", addend_dtype);
     OQ_CHECK_ARG(a_bits >= 2 && a_bits <= 8 && b_bits >= 2 && b_bits <= 8, "oq_gemm_i8: code widths %d / %d (2..8 bit grids)", a_bits, b_bits);
     OQ_CHECK_ARG(lda >= K && ldb >= K && ldc >= N, "oq_gemm_i8: leading dimensions");
     // |sum_k a*b| <= K * 128 * 128 must stay inside int32
     OQ_CHECK_ARG(K <= (1ll << 16), "oq_gemm_i8: K = %lld too long for int32 accumulation", (long long)K);
     GemmI8P p{};
     p.a = (const int8_t*)a_codes; p.b = (const int8_t*)b_codes; p.c = c; p.bias = bias; p.addend = addend;
+    p.add_f32 = addend_dtype == OQ_F32; p.cw32 = c_wide;
     p.sa = a_scale; p.za = a_zp; p.ca = a_csum; p.sw = b_scale; p.zw = b_zp; p.cw = b_csum;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.off_a = a_bits == 8 ? 128.f : 0.f;       // the quantisers store plain grid codes, 8-bit grids as code - 128
     p.off_w = b_bits == 8 ? 128.f : 0.f;
     hipStream_t st = (hipStream_t)stream;
     const bool fast = K % IBK == 0 && lda % 16 == 0 && ldb % 16 == 0 && oq_aligned16(a_codes) && oq_aligned16(b_codes) &&
-                      M >= 8 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && oq_aligned16(c) && (!addend || oq_aligned16(addend)) &&
+                      M >= 8 && N >= 128 && N % 8 == 0 && ldc % 8 == 0 && oq_aligned16(c) && (!addend || oq_aligned16(addend)) && oq_aligned16(c_wide) &&
                       (!bias || oq_aligned16(bias)) && oq_aligned16(b_scale) && oq_aligned16(b_zp) && oq_aligned16(b_csum) &&
                       dbg_env_i8("OQ_GEMM_I8_REF", 0) == 0;
     if (fast) {

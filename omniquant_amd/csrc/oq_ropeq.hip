@@ -36,6 +36,7 @@ struct RQ {
     void *y1, *y2;
     const void *g1, *g2;
     int nh0, nh1, nrope;
+    int grid;           // forward: store the grid coordinates clamp(round(x/s) + z, 0, Q) - z instead of the values (x s)
 };
 
 struct HeadSel {        // which output / gradient tensor a head belongs to, and its index there
@@ -116,6 +117,7 @@ __global__ void __launch_bounds__(256) ropeq_fwd_kernel(RQ p) {
         float inv_s = 0.f;
         const QP q = make_qp(hi, lo, false, 0.f, 0.f, p.nbits, 0, p.inv_q, &inv_s);
         const bool regular = q.s != 0.f && fabsf(q.s) <= 3.4028234663852886e38f && bad == 0.f;
+        const float os = p.grid ? 1.f : q.s;        // (an irregular segment is NaN either way)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             float yv[8];
@@ -124,14 +126,14 @@ __global__ void __launch_bounds__(256) ropeq_fwd_kernel(RQ p) {
                 for (int i = 0; i < 8; ++i) {
                     float tq;
                     const float rq = rne_div(x[c][i], q.s, inv_s, &tq);
-                    yv[i] = (__builtin_amdgcn_fmed3f(rq + q.z, 0.f, Q) - q.z) * q.s;
+                    yv[i] = (__builtin_amdgcn_fmed3f(rq + q.z, 0.f, Q) - q.z) * os;
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     float v = rne_ste(x[c][i] / q.s) + q.z;
                     v = (v != v) ? v : fminf(fmaxf(v, 0.f), Q);
-                    yv[i] = (v - q.z) * q.s;
+                    yv[i] = (v - q.z) * (p.grid ? (q.s != q.s ? NAN : 1.f) : q.s);
                 }
             }
             Vec8<TOUT>::store(yseg + (c * 4 + l) * 8, yv);
@@ -301,12 +303,13 @@ extern "C" int oq_rope_quant_bwd(const void* x, int x_dtype, int64_t rows, int64
 // ---- q, k and v in one launch per direction (same arithmetic as three oq_rope_quant_* calls: q and k rotated, v not) ------
 extern "C" int oq_qkv_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, int64_t T, int nhq, int nhk, int nhv, int hd,
                                      const float* cos, const float* sin, int nbits, void* yq, void* yk, void* yv, int y_dtype,
-                                     float* scale, float* zp, float* xmin, float* xmax, void* stream) {
+                                     int out_grid, float* scale, float* zp, float* xmin, float* xmax, void* stream) {
     OQ_CHECK_ARG(nhq > 0 && nhk > 0 && nhv > 0, "oq_qkv_rope_quant_fwd: head counts %d / %d / %d", nhq, nhk, nhv);
     const int nh = nhq + nhk + nhv;
     const int rc = check("oq_qkv_rope_quant_fwd", rows, T, nh, hd, nbits, cos, sin, true);
     if (rc) return rc;
     OQ_CHECK_ARG(x && yq && yk && yv && cos && sin && (nbits == 16 || (scale && zp && xmin && xmax)), "oq_qkv_rope_quant_fwd: null pointer");
+    OQ_CHECK_ARG(!out_grid || nbits <= 8, "oq_qkv_rope_quant_fwd: grid coordinates are exact in bf16 up to 8 bits, not %d", nbits);
     OQ_CHECK_ARG(oq_aligned16(x) && oq_aligned16(yq) && oq_aligned16(yk) && oq_aligned16(yv) && oq_aligned16(cos) && oq_aligned16(sin),
                  "oq_qkv_rope_quant_fwd: 16-byte alignment");
     RQ p{};
@@ -314,6 +317,7 @@ extern "C" int oq_qkv_rope_quant_fwd(const void* x, int x_dtype, int64_t rows, i
     p.inv_q = 1.0f / (float)((1 << nbits) - 1);
     p.scale = scale; p.zp = zp; p.xmin = xmin; p.xmax = xmax;
     p.nh0 = nhq; p.nh1 = nhk; p.nrope = nhq + nhk;
+    p.grid = out_grid ? 1 : 0;
     const dim3 grid(rq_grid(rows * nh)), blk(256);
     hipStream_t st = (hipStream_t)stream;
     switch (x_dtype * 3 + y_dtype) {

@@ -8,14 +8,21 @@ from . import ops
 from .quantizer import UniformAffineQuantizer
 
 
-def _hip_linear(input, weight, bias=None, residual=None, sib=None):
+def _hip_linear(input, weight, bias=None, residual=None, sib=None, wide=False):
+    """wide: also keep the un-rounded float32 result as `_oq_wide` on the (bf16) output -- integer fprop only (ops.wide_on)."""
     xint, wint = getattr(input, "_oq_int", None), getattr(weight, "_oq_int", None)
     if weight.dtype != input.dtype:
         weight = ops.cast(weight, input.dtype)
     if xint is None or wint is None or not ops.int_fprop_on():
         xint = wint = None
+    stash = None
+    if wide and xint is not None and input.dtype == torch.bfloat16 and ops.wide_on():
+        stash = {"want_wide": True, "res_wide": ops.wide_of(residual) if residual is not None else None}
     # both operands carry their integer codes (ops.IntCodes): the fprop runs on the int8 MFMA, exactly
-    return ops.LinearFn.apply(input, weight, bias, residual, sib, xint, wint)
+    y = ops.LinearFn.apply(input, weight, bias, residual, sib, xint, wint, stash)
+    if stash is not None and stash.get("wide") is not None:
+        y._oq_wide = stash["wide"].view(y.shape)
+    return y
 
 
 class QuantLinear(nn.Module):
@@ -88,9 +95,13 @@ class QuantLinear(nn.Module):
         results are bit-identical)."""
         if self.use_act_quant and not self.disable_input_quant:
             aq = self.act_quantizer
-            if (input.is_cuda and aq.dynamic_method == "per_token" and aq.metric != "fix0to1" and not aq._identity()
-                    and self.int_fprop_eligible(input.dtype) and self.weight_has_codes()):
-                return aq.quantize(input, want_int=True)          # + integer codes for the int8 fprop (same values)
+            if input.is_cuda and aq.dynamic_method == "per_token" and aq.metric != "fix0to1" and not aq._identity():
+                # + integer codes for the int8 fprop (same values) when this linear takes it; read from the input's un-rounded
+                # side channel if it has one (ops.wide_of)
+                want = self.int_fprop_eligible(input.dtype) and self.weight_has_codes()
+                src = ops.wide_of(input) if input.dtype == torch.bfloat16 else None
+                if want or src is not None:
+                    return aq.quantize(input, want_int=want, src=src)
             return aq(input)
         return input
 
@@ -114,17 +125,18 @@ class QuantLinear(nn.Module):
             return self.weight_quantizer.quantize(self.weight, out_dtype=dtype), self.bias
         return self._weight_as(dtype), self.bias
 
-    def forward(self, input: torch.Tensor, input_is_quantized: bool = False, residual=None, sib=None):
+    def forward(self, input: torch.Tensor, input_is_quantized: bool = False, residual=None, sib=None, wide=False):
         """residual (HIP-path extension): added to the output inside the GEMM's store (the block's residual add).
-        sib: ops.SiblingGrads collector of the tensor `input` came from (fused norm -> quant), or None."""
+        sib: ops.SiblingGrads collector of the tensor `input` came from (fused norm -> quant), or None.
+        wide: ask the HIP GEMM for the un-rounded float32 copy of the output (`_oq_wide`, see _hip_linear)."""
         sink = self.__dict__.get("_stat_sink")
         if sink is not None:                        # LET-init statistics ride on the FP teacher pass (actstats.py)
             sink[0].update(sink[1], input)
         weight, bias = self._resolve(input.dtype)
         if not input_is_quantized:
             input = self.quantize_input(input)
-        if sib is not None and self.fwd_func is _hip_linear:
-            return self.fwd_func(input, weight, bias, residual=residual, sib=sib, **self.fwd_kwargs)
+        if (sib is not None or wide) and self.fwd_func is _hip_linear:
+            return self.fwd_func(input, weight, bias, residual=residual, sib=sib, wide=wide, **self.fwd_kwargs)
         if residual is not None:
             return self.fwd_func(input, weight, bias, residual=residual, **self.fwd_kwargs)
         return self.fwd_func(input, weight, bias, **self.fwd_kwargs)

@@ -62,7 +62,7 @@ class QuantLlamaMLP(nn.Module):
                     dq.scale, dq.round_zero_point = stash["scale"], stash["zp"]
                     if stash.get("int") is not None:
                         act._oq_int = stash["int"]
-                return self.down_proj(act, input_is_quantized=bool(nb), residual=residual)
+                return self.down_proj(act, input_is_quantized=bool(nb), residual=residual, wide=True)
         gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq, sib)
         if fuse_q and ops.silu_mul_quant_supported(gate, dq.n_bits):
             # act_fn(gate) * up and the down_proj input quantiser in ONE kernel: the product is never stored
@@ -72,8 +72,8 @@ class QuantLlamaMLP(nn.Module):
             dq.scale, dq.round_zero_point = stash["scale"], stash["zp"]
             if stash.get("int") is not None:
                 act._oq_int = stash["int"]
-            return self.down_proj(act, input_is_quantized=True, residual=residual)
-        return self.down_proj(ops.SiluMulFn.apply(gate, up), residual=residual)   # residual add fused into the GEMM store
+            return self.down_proj(act, input_is_quantized=True, residual=residual, wide=True)
+        return self.down_proj(ops.SiluMulFn.apply(gate, up), residual=residual, wide=True)   # residual add fused into the GEMM store
 
 
 class QuantLlamaAttention(nn.Module):
@@ -166,7 +166,11 @@ class QuantLlamaAttention(nn.Module):
         nh, nkv, hd = self.num_heads, self.num_key_value_heads, self.head_dim
         hq = hidden_states if input_is_quantized else self.q_proj.quantize_input(hidden_states)   # q/k/v share one pass
         cos, sin = self._rope_tables(position_ids, q_len, hidden_states.device)
+        causal = ops.mask_is_causal(attention_mask)   # exact causal mask -> the masked half is skipped everywhere
+        pq = self.pv_matmul.x1_quantizer
+        p_identity = (not self.pv_matmul.use_act_quant) or pq.n_bits >= 16 or not pq.enable
         fused_qkv = self._fused_rope_quant(hq)
+        grid_scales = None
         split_qkv = (not fused_qkv) and self._fused_rope_split(hq)
         if split_qkv:
             wbs = []
@@ -195,10 +199,16 @@ class QuantLlamaAttention(nn.Module):
                 wints = tuple(getattr(w, "_oq_int", None) for w, _ in wbs)
                 if xint is None or any(w is None for w in wints) or not ops.int_fprop_on():
                     xint = wints = None
+                # attention on the head quantisers' integer grid (bf16 production mode, fused causal kernels): q, k, v come back
+                # as grid coordinates, their scales stay in the merged per-(token, head) vector
+                grid = (ops.grid_attention_on() and hq.dtype == torch.bfloat16 and trio[0][1].n_bits <= 8 and p_identity
+                        and bool(causal) and ops.fused_attention_shape_supported(hq.dtype, q_len, hd))
                 q, k, v = ops.QKVRopeQuantFn.apply(hq, wbs[0][0], wbs[0][1], wbs[1][0], wbs[1][1], wbs[2][0], wbs[2][1], cos, sin,
-                                                   trio[0][1].n_bits, hd, stashes, sib, xint, wints)
+                                                   trio[0][1].n_bits, hd, stashes, sib, xint, wints, grid)
                 for (_, qz, _), st in zip(trio, stashes):
                     qz.scale, qz.round_zero_point = st["scale"], st["zp"]
+                if grid:
+                    grid_scales = tuple(st["scale"] for st in stashes)
             else:
                 outs = []
                 for (lin, qz, rot), (w, b) in zip(trio, wbs):
@@ -220,10 +230,13 @@ class QuantLlamaAttention(nn.Module):
                 raise ValueError(f"Attention mask should be of size {(bsz, 1, q_len, q_len)}, but is "
                                  f"{attention_mask.size()}")
             mask = attention_mask            # [bs,1,T,T]: every sample keeps its own mask (ops.SoftmaxFn)
-        causal = ops.mask_is_causal(attention_mask)   # exact causal mask -> the masked half is skipped everywhere
-        pq = self.pv_matmul.x1_quantizer
-        p_identity = (not self.pv_matmul.use_act_quant) or pq.n_bits >= 16 or not pq.enable
-        if p_identity and ops.fused_attention_supported(q, causal):
+        wide = None
+        if grid_scales is not None:
+            # (decided above: exact causal mask, identity p-quantiser, fused kernels cover the shape)
+            stash = {} if ops.wide_on() else None
+            attn = ops.FusedCausalAttnFn.apply(q, k, v, 1.0 / math.sqrt(hd), grid_scales, stash)
+            wide = stash.get("wide") if stash is not None else None
+        elif p_identity and ops.fused_attention_supported(q, causal):
             # exact causal mask + identity p-quantiser (the reference default, 16 bit): one fused kernel per direction,
             # the [nh, T, T] scores / probabilities never touch HBM
             if not fused_qkv:
@@ -236,7 +249,10 @@ class QuantLlamaAttention(nn.Module):
             if not fused_qkv:
                 v = self.pv_matmul.quant_x2(v)
             attn = self.pv_matmul.apply_probs(probs, v, causal)        # [bs, T, nh, hd]
-        attn = self.o_proj(attn.view(bsz, q_len, self.hidden_size), residual=residual)   # (+ residual in the GEMM store)
+        attn = attn.view(bsz, q_len, self.hidden_size)
+        if wide is not None:
+            attn._oq_wide = wide.view(bsz, q_len, self.hidden_size)     # un-rounded output for the o_proj input quantiser
+        attn = self.o_proj(attn, residual=residual, wide=True)           # (+ residual in the GEMM store)
         return attn, None, None
 
     def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):

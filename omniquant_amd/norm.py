@@ -43,7 +43,10 @@ class _FusedQuantMixin:
             weight, bias = _f32_cached(self, "weight"), _f32_cached(self, "bias")
         # integer side channel for the int8 fprop of the linears that read y (ops.IntCodes), when they can use it
         stash = {"want_int": True} if (lin.weight_has_codes() and lin.int_fprop_eligible(x.dtype)) else {}
-        y, res = ops.NormQuantFn.apply(x, weight, bias, eps, is_ln, q.n_bits, stash)
+        wide = ops.wide_of(x) if x.dtype == torch.bfloat16 else None     # un-rounded hidden state (ops.wide_on)
+        y, res = ops.NormQuantFn.apply(x, weight, bias, eps, is_ln, q.n_bits, stash, wide)
+        if wide is not None:
+            res._oq_wide = wide           # the residual path keeps the side channel (down_proj / fc2 add it in float32)
         q.scale, q.round_zero_point = stash["scale"], stash["zp"]
         if stash.get("int") is not None:
             y._oq_int = stash["int"]

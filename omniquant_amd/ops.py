@@ -126,7 +126,14 @@ class FakeQuantFn(torch.autograd.Function):
     non-differentiable side outputs 'scale' and 'zp' ([rows*cols/seg, 1] f32)."""
 
     @staticmethod
-    def forward(ctx, w, col_mul, row_div, row_mul, shift, up, low, nbits, seg, symmetric, out_dtype, stash, out=None):
+    def forward(ctx, w, col_mul, row_div, row_mul, shift, up, low, nbits, seg, symmetric, out_dtype, stash, out=None, src=None):
+        """src: float32 tensor of w's shape holding the same values un-rounded (`_oq_wide`): the kernels read it in place of w;
+        the gradient returned for w keeps w's dtype."""
+        ctx.in_dtype = w.dtype
+        if src is not None:
+            if src.dtype != torch.float32 or src.shape != w.shape or src.device != w.device:
+                raise C.OQError("FakeQuantFn: `src` must be a float32 tensor of the input's shape")
+            w = src
         w = w.contiguous()
         cols = w.shape[-1]
         rows = w.numel() // cols
@@ -241,8 +248,8 @@ class FakeQuantFn(torch.autograd.Function):
             ctx.batch.add_backward(bargs, (w, cm, rd, rm, sh, u, l, xmin, xmax, gy, gws, g_up, g_low, g_cm, g_sh, g_rd, g_rm, ws))
         else:
             C.call("oq_fakequant_bwd", *bargs, C.stream())
-        if gx is not None and gx.dtype != w.dtype:
-            gx = gx.to(w.dtype)
+        if gx is not None and gx.dtype != ctx.in_dtype:
+            gx = gx.to(ctx.in_dtype)
         if r_up is not None:
             g_up = None               # already in the arena
         if r_low is not None:
@@ -253,7 +260,7 @@ class FakeQuantFn(torch.autograd.Function):
                 par._oq_collector.add(par, g)
                 outs[i] = None
         g_cm, g_rd, g_rm, g_sh = outs
-        return gx, g_cm, g_rd, g_rm, g_sh, g_up, g_low, None, None, None, None, None, None
+        return gx, g_cm, g_rd, g_rm, g_sh, g_up, g_low, None, None, None, None, None, None, None
 
 
 def _gradient_routing_on():
@@ -261,11 +268,12 @@ def _gradient_routing_on():
 
 
 def fake_quant(x, nbits, seg=None, up=None, low=None, symmetric=False, out_dtype=None, stash=None,
-               col_mul=None, row_div=None, row_mul=None, shift=None, out=None):
-    """Functional entry: returns y (and wshift when `shift` is given).  out: destination of y (see FakeQuantFn)."""
+               col_mul=None, row_div=None, row_mul=None, shift=None, out=None, src=None):
+    """Functional entry: returns y (and wshift when `shift` is given).  out: destination of y; src: float32 source of the
+    same values (see FakeQuantFn)."""
     seg = seg or x.shape[-1]
     if (seg == x.shape[-1] and seg <= 512 and col_mul is None and row_div is None and row_mul is None
-            and shift is None and up is None and out is None):
+            and shift is None and up is None and out is None and src is None):
         # short rows (per-head quantisation over head_dim): pack several segments into one kernel row so a
         # workgroup streams 2-8 KB instead of 256 B; segments never straddle rows, results are identical.
         nrows = x.numel() // seg
@@ -277,7 +285,7 @@ def fake_quant(x, nbits, seg=None, up=None, low=None, symmetric=False, out_dtype
                                      nbits, seg, symmetric, out_dtype or x.dtype, stash)
             return y.view(x.shape)
     y, wshift = FakeQuantFn.apply(x, col_mul, row_div, row_mul, shift, up, low, nbits, seg, symmetric,
-                                  out_dtype or x.dtype, stash, out)
+                                  out_dtype or x.dtype, stash, out, src)
     return (y, wshift) if shift is not None else y
 
 
@@ -388,6 +396,28 @@ def int_pre_dtype(act_dtype, site="qkv"):
     return torch.float32 if on else act_dtype
 
 
+def wide_on():
+    """Un-rounded float32 side channel (`_oq_wide` on a bf16 tensor) for the activations that reach a 4-bit rounding decision
+    in the bf16 production mode: the fused attention's output in front of the o_proj input quantiser, the two hidden states
+    (o_proj / down_proj output + residual) in front of the second norm's quantiser and of the loss.  The bf16 tensor stays the
+    autograd value (gradients keep flowing in bf16); kernels that know the channel read it instead.  OQ_WIDE=0: A/B switch."""
+    return os.environ.get("OQ_WIDE", "1") != "0"
+
+
+def grid_attention_on():
+    """Fused attention on the head quantisers' integer grid (oq_attn_*_grid): q, k, v are never rounded to 16 bits.
+    OQ_GRID_ATTN=0: A/B switch back to bf16 values."""
+    return os.environ.get("OQ_GRID_ATTN", "1") != "0"
+
+
+def wide_of(t):
+    """The float32 side channel of `t` (same shape), or None."""
+    w = getattr(t, "_oq_wide", None)
+    if w is None or w.dtype != torch.float32 or w.numel() != t.numel() or w.device != t.device or not wide_on():
+        return None
+    return w.view(t.shape)
+
+
 def int_codes_supported(cols, seg, nbits, let):
     return bool(C.size_call("oq_fakequant_codes_supported", int(cols), int(seg), int(nbits), int(bool(let))))
 
@@ -406,10 +436,11 @@ def stacked_int(ints):
     return IntCodes(codes, vecs[0], vecs[1], vecs[2], ints[0].nbits)
 
 
-def gemm_i8(a, b, c, bias=None, addend=None, c_off=0):
+def gemm_i8(a, b, c, bias=None, addend=None, c_off=0, wide=None):
     """c[M, N] = dequant(a)[M, K] @ dequant(b)[N, K]^T + bias (+ addend), contracted exactly on the int8 MFMA (oq_gemm_i8).
     a, b: IntCodes; c: preallocated float32 / bfloat16 GPU tensor -- [M, N], or [M, ldc] with the result written to the
-    column block [c_off, c_off + N) (sibling projections sharing one output buffer)."""
+    column block [c_off, c_off + N) (sibling projections sharing one output buffer).  addend: float32 or bfloat16 [M, N].
+    wide: float32 [M, N] that receives the un-rounded result as well (dense output only)."""
     M, K = a.codes.shape
     N = b.codes.shape[0]
     ldc = c.shape[-1]
@@ -423,10 +454,14 @@ def gemm_i8(a, b, c, bias=None, addend=None, c_off=0):
     for v, n in ((a.scale, M), (a.zp, M), (a.csum, M), (b.scale, N), (b.zp, N), (b.csum, N)):
         if v.numel() != n or v.dtype != torch.float32:
             raise C.OQError("gemm_i8: per-row vectors must be float32 with one entry per row")
-    if addend is not None and (addend.dtype != c.dtype or tuple(addend.shape) != (M, N) or not addend.is_contiguous()):
-        raise C.OQError("gemm_i8: addend must be a contiguous tensor of the output's dtype and shape")
-    C.call("oq_gemm_i8", C.ptr(a.codes), C.ptr(b.codes), c.data_ptr() + c_off * c.element_size(), C.fptr(bias), C.ptr(addend),
-           C.fptr(a.scale), C.fptr(a.zp), C.fptr(a.csum), C.fptr(b.scale), C.fptr(b.zp), C.fptr(b.csum),
+    if addend is not None and (addend.dtype not in (torch.float32, torch.bfloat16) or tuple(addend.shape) != (M, N)
+                               or not addend.is_contiguous()):
+        raise C.OQError("gemm_i8: addend must be a contiguous float32 / bfloat16 tensor of the output's shape")
+    if wide is not None and (wide.dtype != torch.float32 or tuple(wide.shape) != (M, N) or not wide.is_contiguous()
+                             or ldc != N or c_off):
+        raise C.OQError("gemm_i8: the wide copy is a contiguous float32 [M, N] tensor next to a dense output")
+    C.call("oq_gemm_i8", C.ptr(a.codes), C.ptr(b.codes), c.data_ptr() + c_off * c.element_size(), C.fptr(wide), C.fptr(bias),
+           C.ptr(addend), C.dt(addend) if addend is not None else 0, C.fptr(a.scale), C.fptr(a.zp), C.fptr(a.csum), C.fptr(b.scale), C.fptr(b.zp), C.fptr(b.csum),
            M, N, K, K, K, ldc, a.nbits, b.nbits, C.dt(c), C.stream())
 
 
@@ -457,7 +492,9 @@ class LinearFn(torch.autograd.Function):
     models/int_llama_layer.py:246,264 is folded into the GEMM's store) with dgrad / wgrad / bias-grad kernels."""
 
     @staticmethod
-    def forward(ctx, x, wq, bias, residual=None, sib=None, xint=None, wint=None):
+    def forward(ctx, x, wq, bias, residual=None, sib=None, xint=None, wint=None, stash=None):
+        """stash (dict): with "want_wide" the integer fprop also writes its un-rounded float32 result into stash["wide"] (the
+        returned bf16 tensor is its rounded copy), and the residual is read from stash["res_wide"] (float32) when given."""
         ctx.sib = sib
         x2 = x.contiguous().view(-1, x.shape[-1])
         wq = wq.contiguous()
@@ -475,7 +512,13 @@ class LinearFn(torch.autograd.Function):
         if xint is not None and wint is not None and tuple(xint.codes.shape) == (T, K) and tuple(wint.codes.shape) == (N, K):
             # both operands are on quantiser grids: the fprop contracts their integer codes exactly (int8 MFMA); x2 / wq -- the
             # same values rounded to bf16 -- are only the backward's operands
-            gemm_i8(xint, wint, y, bias=b32, addend=res2)
+            wide = None
+            if stash is not None and stash.get("want_wide") and y.dtype == torch.bfloat16:
+                wide = stash["wide"] = torch.empty((T, N), dtype=torch.float32, device=x2.device)
+                rw = stash.get("res_wide")
+                if rw is not None and res2 is not None and rw.numel() == T * N:
+                    res2 = rw.contiguous().view(T, N)
+            gemm_i8(xint, wint, y, bias=b32, addend=res2, wide=wide)
         else:
             gemm(x2, wq, y, T, N, K, K, K, N, True, True, bias=b32, addend=res2)
         ctx.save_for_backward(x2, wq)
@@ -508,7 +551,7 @@ class LinearFn(torch.autograd.Function):
             ws = torch.empty(ws_n, dtype=torch.float32, device=gy2.device)
             C.call("oq_colsum", C.ptr(gy2), C.dt(gy2), T, N, C.fptr(gb), C.fptr(ws), ws_n, C.stream())
         gres = gy if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres, None, None, None
+        return gx, gw, gb, gres, None, None, None, None
 
 
 def rope_quant_supported(dtype, hd):
@@ -593,7 +636,7 @@ class QKVRopeQuantFn(torch.autograd.Function):
     x [bs, T, K]; returns q [bs, T, nhq, hd], k, v [bs, T, nhk|nhv, hd]."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, cos, sin, nbits, hd, stashes, sib=None, xint=None, wints=None):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, cos, sin, nbits, hd, stashes, sib=None, xint=None, wints=None, grid=False):
         ctx.sib = sib
         x2 = x.contiguous().view(-1, x.shape[-1])
         ws = [w.contiguous() for w in (wq, wk, wv)]
@@ -637,8 +680,8 @@ class QKVRopeQuantFn(torch.autograd.Function):
                                  tuple(torch.empty((rows * nht, 1), dtype=torch.float32, device=x2.device) for _ in range(4)))
         T = x.shape[-2]
         C.call("oq_qkv_rope_quant_fwd", C.ptr(pre), C.dt(pre), rows, T, nhs[0], nhs[1], nhs[2], hd, C.fptr(cos), C.fptr(sin),
-               int(nbits), C.ptr(ys[0]), C.ptr(ys[1]), C.ptr(ys[2]), C.dt(ys[0]), C.fptr(scale), C.fptr(zp), C.fptr(xmin),
-               C.fptr(xmax), C.stream())
+               int(nbits), C.ptr(ys[0]), C.ptr(ys[1]), C.ptr(ys[2]), C.dt(ys[0]), int(bool(grid) and not ident), C.fptr(scale),
+               C.fptr(zp), C.fptr(xmin), C.fptr(xmax), C.stream())
         if stashes is not None and not ident:
             h0 = 0
             sv, zv = scale.view(rows, nht, 1), zp.view(rows, nht, 1)
@@ -718,7 +761,7 @@ class QKVRopeQuantFn(torch.autograd.Function):
             for i, (N, off) in enumerate(zip(Ns, offs)):
                 if has_bias[i] and need[2 + 2 * i]:
                     gbs[i] = gb[off:off + N]
-        return (gx, gws[0], gbs[0], gws[1], gbs[1], gws[2], gbs[2], None, None, None, None, None, None, None, None)
+        return (gx, gws[0], gbs[0], gws[1], gbs[1], gws[2], gbs[2], None, None, None, None, None, None, None, None, None)
 
 
 class SiblingLinearFn(torch.autograd.Function):
@@ -942,12 +985,19 @@ class NormQuantFn(torch.autograd.Function):
     kernel).  The normalised row reaches the quantiser in fp32 and is never stored."""
 
     @staticmethod
-    def forward(ctx, x, w, b, eps, is_ln, nbits, stash):
+    def forward(ctx, x, w, b, eps, is_ln, nbits, stash, src=None):
+        """src: float32 tensor holding x's values un-rounded (`_oq_wide`); the kernels read it in place of x, y and the
+        gradients keep x's dtype."""
         x = x.contiguous()
+        xin = x
+        if src is not None:
+            if src.dtype != torch.float32 or src.numel() != x.numel() or x.dtype != torch.bfloat16:
+                raise C.OQError("NormQuantFn: `src` must be a float32 tensor of the (bf16) input's shape")
+            x = src.contiguous().view(x.shape)
         cols = x.shape[-1]
         rows = x.numel() // cols
         w32, b32 = _f32(w), _f32(b)
-        y = torch.empty_like(x)
+        y = torch.empty_like(xin)
         rstd, scale, zp, xmin, xmax = (torch.empty((rows, 1), dtype=torch.float32, device=x.device) for _ in range(5))
         mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if is_ln else None
         codes = csum = None
@@ -965,32 +1015,32 @@ class NormQuantFn(torch.autograd.Function):
             if not os.environ.get("OQ_NO_SIBLING_GRADS"):
                 ctx.sib = stash["sib"] = SiblingGrads()       # hand this to every consumer of y (see SiblingGrads)
         ctx.save_for_backward(x, w32, b32, rstd, mean, xmin, xmax)
-        ctx.cfg = (bool(is_ln), int(nbits), b is not None)
-        return y, x.view_as(x)
+        ctx.cfg = (bool(is_ln), int(nbits), b is not None, xin.dtype)
+        return y, xin.view_as(xin)
 
     @staticmethod
     def backward(ctx, gy, gpass):
         x, w32, b32, rstd, mean, xmin, xmax = ctx.saved_tensors
-        is_ln, nbits, has_b = ctx.cfg
+        is_ln, nbits, has_b, gdt = ctx.cfg          # gdt: the autograd dtype of x (x itself may be its float32 source)
         if gy is None:
-            return gpass, None, None, None, None, None, None
+            return gpass, None, None, None, None, None, None, None
         cols = x.shape[-1]
         rows = x.numel() // cols
         gy = gy.contiguous()
-        if gy.dtype != x.dtype:
-            gy = gy.to(x.dtype)
+        if gy.dtype != gdt:
+            gy = gy.to(gdt)
         if gpass is not None:
             gpass = gpass.contiguous()
-            if gpass.dtype != x.dtype:
-                gpass = gpass.to(x.dtype)
+            if gpass.dtype != gdt:
+                gpass = gpass.to(gdt)
         parts = ctx.sib.take() if ctx.sib is not None else []
         parts = [t.contiguous().view(rows, cols) for t in parts]
-        if any(t.dtype != x.dtype for t in parts) or len(parts) > 2:
-            gy = gy + sum(t.to(x.dtype) for t in parts)            # more pieces than the kernel takes: plain adds
+        if any(t.dtype != gdt for t in parts) or len(parts) > 2:
+            gy = gy + sum(t.to(gdt) for t in parts)            # more pieces than the kernel takes: plain adds
             parts = []
         g2 = parts[0] if len(parts) > 0 else None
         g3 = parts[1] if len(parts) > 1 else None
-        gx = torch.empty_like(x)
+        gx = torch.empty(x.shape, dtype=gdt, device=x.device)
         gw = torch.empty((cols,), dtype=torch.float32, device=x.device)
         gb = torch.empty((cols,), dtype=torch.float32, device=x.device) if (has_b and ctx.needs_input_grad[2]) else None
         ws_n = C.size_call("oq_norm_quant_bwd_workspace", rows, cols)
@@ -998,7 +1048,7 @@ class NormQuantFn(torch.autograd.Function):
         C.call("oq_norm_quant_bwd", C.ptr(x), C.ptr(gy), C.ptr(g2), C.ptr(g3), C.dt(x), C.dt(gy), rows, cols, C.fptr(w32), C.fptr(b32), C.fptr(rstd), C.fptr(mean),
                int(is_ln), nbits, C.fptr(xmin), C.fptr(xmax), C.ptr(gx), C.fptr(gw), C.fptr(gb), C.ptr(gpass), C.fptr(ws), ws_n,
                C.stream())
-        return gx, (gw if ctx.needs_input_grad[1] else None), gb, None, None, None, None
+        return gx, (gw if ctx.needs_input_grad[1] else None), gb, None, None, None, None, None
 
 
 class RopeFn(torch.autograd.Function):
@@ -1275,27 +1325,59 @@ def fused_attention_supported(q, causal):
     return bool(C.size_call("oq_attn_supported", C.dt(q), q.shape[1], q.shape[3], 1))
 
 
+def fused_attention_shape_supported(dtype, T, hd):
+    """fused_attention_supported for a problem whose q does not exist yet (exact causal mask assumed)."""
+    if os.environ.get("OQ_NO_FLASH") or dtype not in C._DT:
+        return False
+    return bool(C.size_call("oq_attn_supported", C._DT[dtype], int(T), int(hd), 1))
+
+
 class FusedCausalAttnFn(torch.autograd.Function):
     """o = softmax(scale * q k^T + causal mask) v without materialising scores / probabilities
     (models/int_llama_layer.py:143-163 with the p-quantiser at its 16-bit identity).  q [bs,T,nh,hd];
-    k, v [bs,T,nkv,hd] -> o [bs,T,nh,hd].  Backward: oq_attn_bwd (dK, dV, dS^T) + one causal oq_gemm for dQ."""
+    k, v [bs,T,nkv,hd] -> o [bs,T,nh,hd].  Backward: oq_attn_bwd (dK, dV, dS^T) + one causal oq_gemm for dQ.
+    grid = (sq, sk, sv): q / k / v hold the head quantisers' grid coordinates (QKVRopeQuantFn(grid=True)) and sq / sk / sv
+    [rows, heads, 1] are views of their merged per-(token, head) scale vector: the products contract the coordinates exactly
+    (oq_attn_*_grid) and the incoming / outgoing gradients are still those of the fake-quantised VALUES.  stash (dict):
+    receives "wide" = the output in float32 (side channel for the o_proj input quantiser; the returned tensor is its bf16 copy)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale):
+    def forward(ctx, q, k, v, scale, grid=None, stash=None):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         bs, T, nh, hd = q.shape
         nkv = k.shape[2]
         o = torch.empty_like(q)
         lse = torch.empty((bs, nh, T), dtype=torch.float32, device=q.device)
-        C.call("oq_attn_fwd", C.ptr(q), C.ptr(k), C.ptr(v), C.ptr(o), C.fptr(lse), C.dt(q), bs, T, nh, nkv, hd,
-               float(scale), 1, C.stream())
-        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.grid = grid is not None
+        if grid is not None:
+            sq, sk, sv = grid
+            ld_s = sq.stride(0)
+            for s_, n in ((sq, nh), (sk, nkv), (sv, nkv)):
+                if (s_.dtype != torch.float32 or tuple(s_.shape[:2]) != (bs * T, n) or s_.stride(0) != ld_s or s_.stride(1) != 1
+                        or q.dtype != torch.bfloat16):
+                    raise C.OQError("FusedCausalAttnFn: grid scales must be float32 [rows, heads(, 1)] views of one merged vector")
+            o32 = torch.empty(q.shape, dtype=torch.float32, device=q.device) if stash is not None else None
+            C.call("oq_attn_fwd_grid", C.ptr(q), C.ptr(k), C.ptr(v), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), ld_s, C.ptr(o),
+                   C.fptr(o32), C.fptr(lse), bs, T, nh, nkv, hd, float(scale), 1, C.stream())
+            if stash is not None:
+                stash["wide"] = o32
+            ctx.has_o32 = o32 is not None
+            ctx.save_for_backward(q, k, v, o, lse, sq, sk, sv, *([o32] if o32 is not None else []))
+        else:
+            C.call("oq_attn_fwd", C.ptr(q), C.ptr(k), C.ptr(v), C.ptr(o), C.fptr(lse), C.dt(q), bs, T, nh, nkv, hd,
+                   float(scale), 1, C.stream())
+            ctx.save_for_backward(q, k, v, o, lse)
         ctx.scale = float(scale)
         return o
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v, o, lse = ctx.saved_tensors
+        o32 = None
+        if ctx.grid:
+            q, k, v, o, lse, sq, sk, sv = ctx.saved_tensors[:8]
+            o32 = ctx.saved_tensors[8] if ctx.has_o32 else None
+        else:
+            q, k, v, o, lse = ctx.saved_tensors
         go = go.contiguous()
         bs, T, nh, hd = q.shape
         nkv = k.shape[2]
@@ -1304,8 +1386,14 @@ class FusedCausalAttnFn(torch.autograd.Function):
         ds_t = torch.empty((bs, nh, T, T), dtype=q.dtype, device=q.device)
         gk_full = torch.empty_like(q)
         gv_full = torch.empty_like(q)
-        C.call("oq_attn_bwd", C.ptr(q), C.ptr(k), C.ptr(v), C.ptr(o), C.ptr(go), C.fptr(lse), C.fptr(dsum), C.ptr(ds_t),
-               C.ptr(gk_full), C.ptr(gv_full), C.dt(q), bs, T, nh, nkv, hd, ctx.scale, 1, C.stream())
+        if ctx.grid:
+            # (ds_t comes back scaled by sk[key]: the dQ GEMM below contracts it with the K coordinates)
+            C.call("oq_attn_bwd_grid", C.ptr(q), C.ptr(k), C.ptr(v), sq.data_ptr(), sk.data_ptr(), sv.data_ptr(), sq.stride(0),
+                   C.ptr(o), C.fptr(o32), C.ptr(go), C.fptr(lse), C.fptr(dsum), C.ptr(ds_t), C.ptr(gk_full), C.ptr(gv_full), bs, T,
+                   nh, nkv, hd, ctx.scale, 1, C.stream())
+        else:
+            C.call("oq_attn_bwd", C.ptr(q), C.ptr(k), C.ptr(v), C.ptr(o), C.ptr(go), C.fptr(lse), C.fptr(dsum), C.ptr(ds_t),
+                   C.ptr(gk_full), C.ptr(gv_full), C.dt(q), bs, T, nh, nkv, hd, ctx.scale, 1, C.stream())
         gq = torch.empty_like(q)
         for b in range(bs):
             # dQ[t,d] = sum_t' dS^T[t',t] K[t',d]   (contraction limited to t' < m0 + tile)
@@ -1316,7 +1404,7 @@ class FusedCausalAttnFn(torch.autograd.Function):
             gk, gv = gk_full, gv_full
         else:
             gk, gv = group_sum(gk_full, nkv, rep, gv_full)       # dK and dV of the shared heads: one launch of ours
-        return gq, gk, gv, None
+        return gq, gk, gv, None, None, None
 
 
 def group_sum(x, nkv, rep, x2=None):
@@ -1375,11 +1463,13 @@ class MSELossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, out, t1, t2):
+        wide = wide_of(out) if out.dtype == torch.bfloat16 else None     # (the block output's un-rounded side channel)
         out, t1 = out.contiguous(), t1.contiguous()
         t2 = t2.contiguous() if t2 is not None else None
         loss = torch.empty((1 + 1024,), dtype=torch.float32, device=out.device)       # [0] result, [1:] kernel scratch
         g = torch.empty_like(out)
-        C.call("oq_mse_fwd_bwd", C.ptr(out), C.ptr(t1), C.ptr(t2), C.dt(out), out.numel(), 1.0, C.fptr(loss), C.ptr(g),
+        src = wide.contiguous() if wide is not None else out
+        C.call("oq_mse_fwd_bwd", C.ptr(src), C.dt(src), C.ptr(t1), C.ptr(t2), C.dt(out), out.numel(), 1.0, C.fptr(loss), C.ptr(g),
                C.stream())
         ctx.save_for_backward(g)
         return loss[0]

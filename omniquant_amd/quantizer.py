@@ -68,7 +68,8 @@ class UniformAffineQuantizer(nn.Module):
     def _identity(self):
         return self.n_bits >= 16 or not self.enable
 
-    def quantize(self, x, out_dtype=None, col_mul=None, row_div=None, row_mul=None, shift=None, out=None, want_int=False):
+    def quantize(self, x, out_dtype=None, col_mul=None, row_div=None, row_mul=None, shift=None, out=None, want_int=False,
+                 src=None):
         """Dynamic calibration + fake quant in ONE kernel, optionally fused with the LET weight transform
         x' = ((x*col_mul)/row_div)*row_mul and the by-product x @ shift.  Sets self.scale/round_zero_point.
 
@@ -80,7 +81,8 @@ class UniformAffineQuantizer(nn.Module):
         out: destination tensor of the fake-quantised values (block_common stacks sibling weights in one buffer); ignored
         by the identity branch.
         want_int: also produce the integer side channel (ops.IntCodes: the grid codes as int8 + per-row code sums) when the
-        kernels can; it is attached to the returned tensor as `_oq_int` and kept in `self.int_codes` (None when not produced)."""
+        kernels can; it is attached to the returned tensor as `_oq_int` and kept in `self.int_codes` (None when not produced).
+        src: float32 tensor with x's values before their rounding to 16 bits (ops.wide_of): the kernel reads it in place of x."""
         let = not (col_mul is None and row_div is None and row_mul is None and shift is None)
         self.int_codes = None
         if self._identity():
@@ -96,7 +98,7 @@ class UniformAffineQuantizer(nn.Module):
         if self.group_size and x.shape[-1] % seg != 0:
             assert self.symmetric, "ragged weight groups are only defined for the symmetric grid (quantizer.py:69)"
         res = ops.fake_quant(x, self.n_bits, seg, up, low, self.symmetric, out_dtype, stash,
-                             col_mul, row_div, row_mul, shift, out=out)
+                             col_mul, row_div, row_mul, shift, out=out, src=src)
         self.scale, self.round_zero_point = stash["scale"], stash["zp"]
         ic = stash.get("int")
         if ic is not None:

@@ -162,21 +162,24 @@ class _FusedAttnModel(torch.autograd.Function):
     backward as the kernel does it: P = softmax (fp32, recomputed), dV = P_r^T dO with P rounded, dP = dO v^T,
              D = rowsum(dO * O_r) with the STORED output, dS = scale * P * (dP - D) rounded to `dtype` (the kernel keeps
              dS^T in bf16 for both dK and the dQ GEMM), dQ = dS k, dK = dS^T q.
-    The mathematics is that of models/int_llama_layer.py:143-163; only the rounding points are the kernel's."""
+    The mathematics is that of models/int_llama_layer.py:143-163; only the rounding points are the kernel's.
+    grid: the kernels' integer-grid mode (oq_attn_*_grid) -- the forward rounds nothing (q, k, v arrive as exact grid
+    coordinates x scale, the probabilities meet v as a bf16 high + low pair = 16 mantissa bits, the output is handed on in
+    fp32); the backward keeps its rounding points (dO, P for dV, dS) except that D uses the un-rounded output."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, scale, dtype):
+    def forward(ctx, q, k, v, mask, scale, dtype, grid=False):
         s = torch.matmul(q, k.transpose(2, 3)) * scale
         if mask is not None:
             s = torch.max(s + mask, torch.tensor(torch.finfo(s.dtype).min))
         pt = torch.exp(s - s.amax(dim=-1, keepdim=True))
         l = pt.sum(dim=-1, keepdim=True)
-        o = torch.matmul(pt.to(dtype).to(pt.dtype), v) / l
+        o = torch.matmul(pt if grid else pt.to(dtype).to(pt.dtype), v) / l
         orr = o.to(dtype).to(o.dtype)
         p = pt / l
-        ctx.save_for_backward(q, k, v, p, orr)
+        ctx.save_for_backward(q, k, v, p, o if grid else orr)       # (grid: D is taken from the un-rounded output)
         ctx.scale, ctx.dtype = scale, dtype
-        return orr
+        return o if grid else orr
 
     @staticmethod
     def backward(ctx, go):
@@ -189,7 +192,7 @@ class _FusedAttnModel(torch.autograd.Function):
         ds = (p * (dp - d) * ctx.scale).to(dt).to(p.dtype)
         dq = torch.matmul(ds, k)
         dk = torch.matmul(ds.transpose(2, 3), q)
-        return dq, dk, dv, None, None, None
+        return dq, dk, dv, None, None, None, None
 
 
 class _IntFpropLinear(torch.autograd.Function):
@@ -461,7 +464,7 @@ class Block:
             return _GradRoundSTE.apply(y, int_dtype)        # value kept in fp32 for a fused quantiser, its gradient is stored in bf16
         return y
 
-    def forward(self, x, mask=None, position_ids=None, temps=None, act_quant=True, act_dtype=None, int_fprop=False):
+    def forward(self, x, mask=None, position_ids=None, temps=None, act_quant=True, act_dtype=None, int_fprop=False, wide=False):
         """x [bs,T,H].  temps=None -> raw (or folded) weights; act_quant toggles every activation quantizer.
         act_dtype (precision-mode emulation only, default None = the reference's fp32 arithmetic): every activation the
         product path materialises between two kernels is rounded to that dtype (value and gradient), arithmetic stays
@@ -469,7 +472,11 @@ class Block:
         int_fprop (with act_dtype, weight-activation configurations on grids of at most 8 bits without weight groups): the
         product path's integer fprop -- every Linear's forward product is exact (_IntFpropLinear; `temps` must come from
         temporaries(int_fprop=True)), and the q | k | v projection output, which feeds the fused RoPE -> head quantisers, stays
-        fp32 (head_dim 128)."""
+        fp32 (head_dim 128).
+        wide (llama, head_dim 128): the product path's un-rounded side channels in front of every remaining 4-bit rounding
+        decision -- the fused attention on the head quantisers' integer grid (q, k, v never rounded, output handed to the
+        o_proj input quantiser in fp32) and, with int_fprop, the two hidden states (o_proj / down_proj output + residual) kept
+        in fp32 next to their bf16 copies; the GRADIENTS of those tensors are still stored in `act_dtype`."""
         nm = self.names
         bs, T, H = x.shape
         R_ = _rounder(act_dtype)
@@ -487,6 +494,8 @@ class Block:
             # projection output in one kernel: the rotated tensor is never stored
             keep = act_dtype is not None and aq4 and self.hd == 128
             pre_f32 = idt is not None and keep          # integer path: the projection output reaches the fused quantiser in fp32
+            wd = bool(wide) and keep and mask is not None         # grid attention (the causal fused kernels) + its fp32 output
+            wd_h = bool(wide) and idt is not None                 # fp32 hidden states: written by the integer fprop's epilogue
             q = self._lin(h, nm["q"], temps, act_quant, rnd, round_out=not pre_f32, int_dtype=idt).view(bs, T, self.nh, self.hd).transpose(1, 2)
             k = self._lin(h, nm["k"], temps, act_quant, rnd, round_out=not pre_f32, int_dtype=idt).view(bs, T, self.nkv, self.hd).transpose(1, 2)
             v = self._lin(h, nm["v"], temps, act_quant, rnd, round_out=not pre_f32, int_dtype=idt).view(bs, T, self.nkv, self.hd).transpose(1, 2)
@@ -501,15 +510,18 @@ class Block:
                 k = k[:, :, None].expand(bs, self.nkv, rep, T, self.hd).reshape(bs, self.nh, T, self.hd)
                 v = v[:, :, None].expand(bs, self.nkv, rep, T, self.hd).reshape(bs, self.nh, T, self.hd)
             q, k = self._aq(q, act_quant), self._aq(k, act_quant)
+            GR_ = (lambda t_: _GradRoundSTE.apply(t_, act_dtype)) if wd else None
             if aq4:
-                q, k = R_(q), R_(k)
+                q, k = (GR_(q), GR_(k)) if wd else (R_(q), R_(k))
             v = self._aq(v, act_quant)
             if aq4:
-                v = R_(v)
+                v = GR_(v) if wd else R_(v)
             if act_dtype is not None and self.hd == 128:
                 # the product path's fused kernels (bf16, head_dim 128, causal): their own rounding points
-                o = _FusedAttnModel.apply(q, k, v, mask, 1.0 / math.sqrt(self.hd), act_dtype)
+                o = _FusedAttnModel.apply(q, k, v, mask, 1.0 / math.sqrt(self.hd), act_dtype, wd)
                 o = o.transpose(1, 2).reshape(bs, T, H)
+                if wd:
+                    o = GR_(o)
             else:
                 att = R_(torch.matmul(q, k.transpose(2, 3))) / math.sqrt(self.hd) if act_dtype is not None else \
                     torch.matmul(q, k.transpose(2, 3)) / math.sqrt(self.hd)
@@ -518,7 +530,8 @@ class Block:
                     att = torch.max(att, torch.tensor(torch.finfo(att.dtype).min))
                 att = F.softmax(att, dim=-1, dtype=torch.float32).to(q.dtype)
                 o = R_(torch.matmul(R_(att), v).transpose(1, 2).reshape(bs, T, H))
-            h = self._lin(o, nm["o"], temps, act_quant, rnd, residual=x, int_dtype=idt)
+            # (the first hidden state's side channel is read by the fused norm -> quantiser kernel; the plain norm reads bf16)
+            h = self._lin(o, nm["o"], temps, act_quant, rnd, residual=x, int_dtype=idt, round_out=not (wd_h and fused_nq))
             h2 = self._norm(h, nm["ln2"], temps)
             if not fused_nq:
                 h2 = R_(h2)
@@ -529,7 +542,7 @@ class Block:
             if not aq4:
                 act = R_(act)          # stored before the GEMM; with activation quantisation on, the product path fuses
                 #                        silu*up into the down_proj input quantiser and the product stays fp32
-            return self._lin(act, "mlp.down_proj", temps, act_quant, rnd, residual=h, int_dtype=idt)
+            return self._lin(act, "mlp.down_proj", temps, act_quant, rnd, residual=h, int_dtype=idt, round_out=not wd_h)
         # ---- OPT: q/k/v are quantised per token over the full hidden dim before the head split
         scaling = self.hd ** -0.5
         q = self._aq(R_(self._lin(h, nm["q"], temps, act_quant, rnd) * scaling), act_quant)

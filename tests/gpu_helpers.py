@@ -167,8 +167,9 @@ def oracle_step_bf16_model(g, meta):
     use_int = (ops.int_fprop_on() and meta["abits"] <= 8 and meta["wbits"] <= 8 and not meta["group_size"]
                and all(c % 128 == 0 and ops.int_codes_supported(c, c, meta["wbits"], False) and ops.int_codes_supported(c, c, meta["wbits"], True)
                        for c in cols))
+    wide = ops.wide_on() and ops.grid_attention_on()                     # the product's un-rounded side channels
     temps = blk.temporaries(store_dtype=bf, int_fprop=use_int)
-    out = blk.forward(x, mask, pos, temps=temps, act_quant=True, act_dtype=bf, int_fprop=use_int)
+    out = blk.forward(x, mask, pos, temps=temps, act_quant=True, act_dtype=bf, int_fprop=use_int, wide=wide)
     loss = torch.nn.functional.mse_loss(tgt, out)
     loss.backward()
     return float(loss.detach()), {n: p.grad.detach().clone() for n, p in blk.params.items()}

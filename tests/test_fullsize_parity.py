@@ -98,8 +98,9 @@ def test_production_step_vs_oracle(name):
         bf = torch.bfloat16
         from omniquant_amd import ops as _ops
         use_int = _ops.int_fprop_on() and group is None and abits <= 8 and wbits <= 8       # the product's integer fprop (oq_gemm_i8)
+        wide = _ops.wide_on() and _ops.grid_attention_on()                   # the product's un-rounded side channels
         temps2 = blk2.temporaries(store_dtype=bf, int_fprop=use_int)
-        out2 = blk2.forward(x.to(bf).float(), mask, pos, temps=temps2, act_quant=True, act_dtype=bf, int_fprop=use_int)
+        out2 = blk2.forward(x.to(bf).float(), mask, pos, temps=temps2, act_quant=True, act_dtype=bf, int_fprop=use_int, wide=wide)
         loss_e = torch.nn.functional.mse_loss(tgt.to(bf).float(), out2)
         loss_e.backward()
         emu_grad = {n: p.grad.detach().clone() for n, p in blk2.params.items()}

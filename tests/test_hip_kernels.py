@@ -338,7 +338,8 @@ def test_rope_silu_relu_softmax_mse(dtype):
     loss = torch.zeros(1 + 1024, device=DEV)
     gg = torch.empty(8, 64, dtype=dtype, device=DEV)
     o_d, t1_d, t2_d = out.to(DEV), t1.to(DEV), t2.to(DEV)
-    C.call("oq_mse_fwd_bwd", C.ptr(o_d), C.ptr(t1_d), C.ptr(t2_d), C.dt(o_d), out.numel(), 1.0, C.fptr(loss), C.ptr(gg), C.stream())
+    C.call("oq_mse_fwd_bwd", C.ptr(o_d), C.dt(o_d), C.ptr(t1_d), C.ptr(t2_d), C.dt(o_d), out.numel(), 1.0, C.fptr(loss), C.ptr(gg),
+           C.stream())
     ol = out.float().clone().requires_grad_(True)
     lr = torch.nn.functional.mse_loss(t1.float(), ol) + torch.nn.functional.mse_loss(t2.float(), ol)
     lr.backward()

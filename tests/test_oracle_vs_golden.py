@@ -119,10 +119,10 @@ def test_block_step(fname):
 
 @pytest.mark.parametrize("fname", ["g3_step_llama_hd128_w4a4_lwc_let.npz", "g3_step_llama_w4a4_lwc_let.npz",
                                    "g3_step_opt_w4a4_lwc_let.npz"])
-@pytest.mark.parametrize("int_fprop", [False, True])
-def test_storage_model_is_the_pinned_step_when_nothing_is_rounded(fname, int_fprop):
-    """The precision-mode emulation of oracle/ref_cpu.py (Block.forward(act_dtype=..., int_fprop=...), temporaries(store_dtype,
-    int_fprop)) is what the production-mode GPU tests are held against.  It must be the reference-pinned fp32 step in
+@pytest.mark.parametrize("int_fprop,wide", [(False, False), (True, False), (True, True)])
+def test_storage_model_is_the_pinned_step_when_nothing_is_rounded(fname, int_fprop, wide):
+    """The precision-mode emulation of oracle/ref_cpu.py (Block.forward(act_dtype=..., int_fprop=..., wide=...),
+    temporaries(store_dtype, int_fprop)) is what the production-mode GPU tests are held against.  It must be the reference-pinned fp32 step in
     everything but its rounding points: with float32 as the "storage" dtype every rounding is the identity, and the model
     -- fused-attention branch, integer-fprop Linear (_IntFpropLinear), fused producer branches and all -- has to reproduce
     the golden step: output, loss and every gradient, at the fixture's own tolerances."""
@@ -131,7 +131,7 @@ def test_storage_model_is_the_pinned_step_when_nothing_is_rounded(fname, int_fpr
     x, tgt, mask = T(g["x"]), T(g["target"]), T(g["mask"])
     pos = torch.from_numpy(g["position_ids"])
     temps = blk.temporaries(store_dtype=torch.float32, int_fprop=int_fprop)
-    out = blk.forward(x, mask, pos, temps=temps, act_quant=True, act_dtype=torch.float32, int_fprop=int_fprop)
+    out = blk.forward(x, mask, pos, temps=temps, act_quant=True, act_dtype=torch.float32, int_fprop=int_fprop, wide=wide)
     # (the model's fused-attention branch evaluates the softmax as exp(s - max) / sum: fp32 op-order noise of a few 1e-5)
     close(out.detach(), g["out"], rtol=1e-3, atol=1e-4, what="out")
     loss = torch.nn.functional.mse_loss(tgt, out)
