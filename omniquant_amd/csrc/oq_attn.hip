@@ -121,10 +121,11 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // GRID: the operands are integer grid coordinates; the S^T block is scaled by sk[key] (ksc[0..63]) here and by
 // c2q[qb] = scale * log2e * sq[query] in the exponent, the probabilities by sv[key] (ksc[64..127]) and split into a bf16 high
 // and low part (two MFMAs per block: 16 mantissa bits instead of 8 in front of the exact integer V operand).
-template <bool DIAG, bool GRID>
+// MID: called between the S^T MFMAs and the softmax (the kernel stores the next K tile and starts loading the next V tile there).
+template <bool DIAG, bool GRID, typename MID>
 __device__ __forceinline__ void fwd_tile(const char* Ks, const char* Vs, const bf16x8 (&qf)[2][4], f32x4 (&o)[2][8],
                                          float (&m)[2], float (&l)[2], const int (&dq)[2], const float (&c2q)[2],
-                                         const float* ksc, int lane) {
+                                         const float* ksc, int lane, MID&& mid) {
     f32x4 st[4][2];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -142,6 +143,7 @@ __device__ __forceinline__ void fwd_tile(const char* Ks, const char* Vs, const b
         st[kb][0] = MFMA(kf[it & 1], qf[0][ks], st[kb][0]);     // S^T block: row = key 16kb+4g+i, col = query
         st[kb][1] = MFMA(kf[it & 1], qf[1][ks], st[kb][1]);
     }
+    mid();
     bf16x8 vf[2];
     vf[0] = frag_tr(Vs, 0, 0, lane);             // in flight under the softmax arithmetic
     if (GRID) {
@@ -280,35 +282,43 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnP p, int nqt, int 
         c2q[1] *= sqp[(int64_t)(qw0 + 16 + c) * p.lds];
     }
     float rsc = 0.f;
-    u32x4 rk[4], rv[4];
-    tile_gload(kp, ldk, tid, rk);
-    tile_gload(vp, ldk, tid, rv);
+    // staging registers are shared by K and V (16 instead of 32): K(j+1) is loaded before the S^T MFMAs of tile j and stored
+    // behind them, V(j+1) is loaded then and stored behind the P V MFMAs
+    u32x4 rr[4];
+    tile_gload(kp, ldk, tid, rr);
     if (GRID && tid < 128) rsc = kscp[(int64_t)(tid & 63) * p.lds];
-    tile_sstore(smem, tid, rk);
-    tile_sstore(smem + TILE, tid, rv);
+    tile_sstore(smem, tid, rr);
+    tile_gload(vp, ldk, tid, rr);
     if (GRID && tid < 128) kscs[tid] = rsc;
+    tile_sstore(smem + TILE, tid, rr);
     __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): nothing (q fragments included) is pending at loop entry
     __syncthreads();
     for (int j = 0; j < ntiles; ++j) {
         const int cur = j & 1;
-        if (j + 1 < ntiles) {
-            tile_gload(kp + (int64_t)(64 * (j + 1)) * ldk, ldk, tid, rk);
-            tile_gload(vp + (int64_t)(64 * (j + 1)) * ldk, ldk, tid, rv);
+        const bool more = j + 1 < ntiles;
+        if (more) {
+            tile_gload(kp + (int64_t)(64 * (j + 1)) * ldk, ldk, tid, rr);
             if (GRID && tid < 128) rsc = kscp[(int64_t)(64 * (j + 1) + (tid & 63)) * p.lds];
         }
         const char* Ks = smem + cur * 2 * TILE;
         const char* Vs = Ks + TILE;
+        char* nxt = smem + (cur ^ 1) * 2 * TILE;
+        auto mid = [&]() {
+            if (more) {
+                tile_sstore(nxt, tid, rr);
+                if (GRID && tid < 128) kscs[(cur ^ 1) * 128 + tid] = rsc;
+                tile_gload(vp + (int64_t)(64 * (j + 1)) * ldk, ldk, tid, rr);
+            }
+        };
         const int kpos0 = 64 * j;
         if (kpos0 <= qw0 + 31) {     // wave-uniform: this wave has at least one unmasked (query, key) pair in the tile
             const int dq[2] = {qw0 + c - kpos0 - 4 * g, qw0 + 16 + c - kpos0 - 4 * g};
-            if (kpos0 + 63 > qw0) fwd_tile<true, GRID>(Ks, Vs, qf, o, m, l, dq, c2q, kscs + cur * 128, lane);
-            else fwd_tile<false, GRID>(Ks, Vs, qf, o, m, l, dq, c2q, kscs + cur * 128, lane);
+            if (kpos0 + 63 > qw0) fwd_tile<true, GRID>(Ks, Vs, qf, o, m, l, dq, c2q, kscs + cur * 128, lane, mid);
+            else fwd_tile<false, GRID>(Ks, Vs, qf, o, m, l, dq, c2q, kscs + cur * 128, lane, mid);
+        } else {
+            mid();
         }
-        if (j + 1 < ntiles) {
-            tile_sstore(smem + (cur ^ 1) * 2 * TILE, tid, rk);
-            tile_sstore(smem + (cur ^ 1) * 2 * TILE + TILE, tid, rv);
-            if (GRID && tid < 128) kscs[(cur ^ 1) * 128 + tid] = rsc;
-        }
+        if (more) tile_sstore(nxt + TILE, tid, rr);
         __syncthreads();
     }
     bf16_t* op = p.o + ((int64_t)b * p.T) * ldq + (int64_t)h * HD;

@@ -36,6 +36,8 @@ class QuantLlamaMLP(nn.Module):
 
     def forward(self, x, residual=None, input_is_quantized=False, sib=None):
         from .linear import _hip_linear
+        # the block OUTPUT feeds no rounding decision (only the loss): its float32 side channel is off unless asked for
+        wide_out = os.environ.get("OQ_WIDE_OUT", "0") != "0"
         xq = x if input_is_quantized else self.gate_proj.quantize_input(x)   # gate/up share one act-quant pass
         dq = self.down_proj.act_quantizer
         fuse_q = (self.down_proj.use_act_quant and dq is not None and not self.down_proj.disable_input_quant and dq.enable
@@ -62,7 +64,7 @@ class QuantLlamaMLP(nn.Module):
                     dq.scale, dq.round_zero_point = stash["scale"], stash["zp"]
                     if stash.get("int") is not None:
                         act._oq_int = stash["int"]
-                return self.down_proj(act, input_is_quantized=bool(nb), residual=residual, wide=True)
+                return self.down_proj(act, input_is_quantized=bool(nb), residual=residual, wide=wide_out)
         gate, up = QuantLinear.forward_siblings([self.gate_proj, self.up_proj], xq, sib)
         if fuse_q and ops.silu_mul_quant_supported(gate, dq.n_bits):
             # act_fn(gate) * up and the down_proj input quantiser in ONE kernel: the product is never stored
@@ -72,8 +74,8 @@ class QuantLlamaMLP(nn.Module):
             dq.scale, dq.round_zero_point = stash["scale"], stash["zp"]
             if stash.get("int") is not None:
                 act._oq_int = stash["int"]
-            return self.down_proj(act, input_is_quantized=True, residual=residual, wide=True)
-        return self.down_proj(ops.SiluMulFn.apply(gate, up), residual=residual, wide=True)   # residual add fused into the GEMM store
+            return self.down_proj(act, input_is_quantized=True, residual=residual, wide=wide_out)
+        return self.down_proj(ops.SiluMulFn.apply(gate, up), residual=residual, wide=wide_out)   # residual add fused into the GEMM store
 
 
 class QuantLlamaAttention(nn.Module):

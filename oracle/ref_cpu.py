@@ -475,8 +475,9 @@ class Block:
         fp32 (head_dim 128).
         wide (llama, head_dim 128): the product path's un-rounded side channels in front of every remaining 4-bit rounding
         decision -- the fused attention on the head quantisers' integer grid (q, k, v never rounded, output handed to the
-        o_proj input quantiser in fp32) and, with int_fprop, the two hidden states (o_proj / down_proj output + residual) kept
-        in fp32 next to their bf16 copies; the GRADIENTS of those tensors are still stored in `act_dtype`."""
+        o_proj input quantiser in fp32) and, with int_fprop, the hidden state after attention (o_proj output + residual) kept
+        in fp32 next to its bf16 copy for the second norm -> quantiser and the down_proj residual add; the GRADIENTS of those
+        tensors are still stored in `act_dtype`."""
         nm = self.names
         bs, T, H = x.shape
         R_ = _rounder(act_dtype)
@@ -542,7 +543,7 @@ class Block:
             if not aq4:
                 act = R_(act)          # stored before the GEMM; with activation quantisation on, the product path fuses
                 #                        silu*up into the down_proj input quantiser and the product stays fp32
-            return self._lin(act, "mlp.down_proj", temps, act_quant, rnd, residual=h, int_dtype=idt, round_out=not wd_h)
+            return self._lin(act, "mlp.down_proj", temps, act_quant, rnd, residual=h, int_dtype=idt)     # (the block output feeds no rounding decision: bf16, as stored)
         # ---- OPT: q/k/v are quantised per token over the full hidden dim before the head split
         scaling = self.hd ** -0.5
         q = self._aq(R_(self._lin(h, nm["q"], temps, act_quant, rnd) * scaling), act_quant)

@@ -10,17 +10,16 @@ Compared (reference step: quantize/omniquant.py:214-230):
   * the fake-quantised temporary weights (`temp_weight`, models/int_llama_layer.py:279-307) of every linear: within one
     bf16 ulp of the oracle's fp32 values, except the rare elements whose rounding decision sits on a tie.
 
-Bar: loss <= 1e-2 relative, gradient cosine >= 0.99, relative L2 <= 5e-2 per tensor.
-  * Weight-only configurations (W3A16g128, W2A16g64): held against the oracle's plain fp32 step.
-  * Weight-activation configurations (W4A4): a bf16-rounded activation sits on the other side of a 4-bit rounding
-    boundary for ~3 % of the elements an fp32 run sees, so gradients that consist of quantisation residue (everything
-    behind the per-head 4-bit q/k quantisers) decorrelate from an fp32 run BY PRECISION MODE, not by kernel error --
-    the reference's own fp16-autocast GPU run differs from its fp32 CPU run the same way.  To verify the kernels
-    nevertheless, the oracle runs the step a second time with every tensor the product path materialises rounded to
-    bf16 (value and gradient; arithmetic still fp32: `Block.forward(act_dtype=torch.bfloat16)`, incl. the fused
-    attention kernels' own rounding points), and the bar is held against THAT step (thresholds in the loop below; the
-    attention-score path is noisier).  Against the plain fp32 step the loss bar is held and the gradient agreement is
-    recorded in the report.
+Bar, against the oracle's PLAIN fp32 step: loss <= 1.5e-3 relative; per gradient tensor
+  * weight-only configurations (W3A16g128, W2A16g64): cosine >= 0.99, relative L2 <= 5e-2;
+  * weight-activation configurations (W4A4): cosine >= 0.99 / L2 <= 0.12, on the attention-score path (everything behind the
+    per-head 4-bit q / k quantisers) cosine >= 0.985 / L2 <= 0.18 -- the level at which the fp32 step agrees with a float64
+    evaluation of itself (0.984 .. 0.987, tests/diag/fp32_vs_fp64.py).  The production mode reaches it because no activation
+    is rounded to 16 bits in front of a 4-bit rounding decision: integer fprop, attention on the integer grid, fp32 side
+    channels for the attention output and the hidden states.  The same bars are held against the oracle's STORAGE MODEL of
+    the product path (`Block.forward(act_dtype=torch.bfloat16, int_fprop=True, wide=True)`: fp32 arithmetic, every tensor
+    the product materialises in bf16 rounded, value and gradient).  With the A/B switches that put 16-bit tensors back
+    (OQ_WIDE=0, OQ_GRID_ATTN=0, OQ_INT_FPROP=0) only the storage-model bar and a coarse floor against fp32 apply.
 Measured values are printed and written to gpurun_out/fullsize_parity.json when that directory exists.
 Every shape is the full one (T = 2048; the LLaMA-2-70B block's CPU step takes about a minute on the GPU box's host cores)."""
 import json
@@ -90,7 +89,7 @@ def test_production_step_vs_oracle(name):
     del temps, out
     t_cpu = time.time() - t0
     # ---- oracle again in the bf16 storage model (weight-activation configurations only) ------------------------------
-    emu_grad, loss_e, use_int = None, None, False
+    emu_grad, loss_e, use_int, wide = None, None, False, False
     if abits < 16:
         blk2 = R.Block("llama", cd, weights, R.QuantSpec(wbits, abits, group, True, let), max_pos=T)
         if let:
@@ -98,7 +97,7 @@ def test_production_step_vs_oracle(name):
         bf = torch.bfloat16
         from omniquant_amd import ops as _ops
         use_int = _ops.int_fprop_on() and group is None and abits <= 8 and wbits <= 8       # the product's integer fprop (oq_gemm_i8)
-        wide = _ops.wide_on() and _ops.grid_attention_on()                   # the product's un-rounded side channels
+        wide = use_int and _ops.wide_on() and _ops.grid_attention_on()       # the product's un-rounded side channels
         temps2 = blk2.temporaries(store_dtype=bf, int_fprop=use_int)
         out2 = blk2.forward(x.to(bf).float(), mask, pos, temps=temps2, act_quant=True, act_dtype=bf, int_fprop=use_int, wide=wide)
         loss_e = torch.nn.functional.mse_loss(tgt.to(bf).float(), out2)
@@ -140,30 +139,36 @@ def test_production_step_vs_oracle(name):
             rep["grads"][n].update({"cos_bf16_model": cos, "l2_bf16_model": l2})
             c2, l22 = cmp(emu_grad[n], ref_grad[n])
             rep["grads"][n].update({"oracle_bf16_vs_fp32_cos": c2, "oracle_bf16_vs_fp32_l2": l22})
-        # Weight-only configurations and everything outside the attention-score path hold the round-2 bar (cosine 0.99,
-        # relative L2 0.05 .. 0.1).  The gradients that pass through softmax(q k^T) with 4-bit q / k -- q_proj, k_proj, the
-        # q/k smoothing vector, and v_proj behind P -- are differences of nearly equal numbers in saturated attention
-        # rows (dS = P (dP - rowsum(dO O)), O stored in bf16): the storage model reproduces the kernel's rounding points
-        # but not its online-softmax tile order, which moves that noise floor.  Measured 0.978 .. 0.989 / 0.15 .. 0.21.
-        if emu_grad is not None and any(t in n for t in ("q_proj", "k_proj", "qkt_smooth")):
-            ok = cos >= 0.97 and l2 <= 0.25
-        elif emu_grad is not None and ("v_proj" in n or "out_smooth" in n):      # behind P @ V as well
-            ok = cos >= 0.98 and l2 <= 0.2
-        elif emu_grad is not None:
-            ok = cos >= 0.995 and l2 <= 0.1
-        else:
+        score = any(t in n for t in ("q_proj", "k_proj", "qkt_smooth"))
+        if emu_grad is None:
+            # weight-only configurations: held against the oracle's plain fp32 step
             ok = cos >= 0.99 and l2 <= 5e-2
-        if not ok:
-            fails.append((n, round(cos, 5), round(l2, 4)))
-        # Regression floor against the PLAIN fp32 oracle step (same bf16-representable inputs), whatever the storage model says:
-        # measured this round with the integer fprop -- 7B: 0.923 .. 0.938 on the attention-score path, >= 0.993 elsewhere; 13B:
-        # 0.899 .. 0.906, 0.93 (v_proj) / 0.968 (out_smooth_scale), >= 0.984 elsewhere.  What is left on the score path is the
-        # 16-bit attention itself (bf16 q / k / v operands, P, dS: tests/diag/rounding_points.py), as in the reference's fp16 run.
-        if emu_grad is not None:
+        elif wide:
+            # Integer fprop + attention on the integer grid + fp32 side channels: no activation is rounded to 16 bits in front of
+            # a 4-bit rounding decision any more (gate | up excepted), and the bar is held against the PLAIN fp32 oracle step as
+            # well as against the storage model.  Measured: 7B 0.9924 .. 0.9934 on the attention-score path (relative L2 0.115 ..
+            # 0.123), >= 0.9991 elsewhere; 13B 0.9940 .. 0.9945 / >= 0.9962.  The fp32 step itself is only defined to that
+            # accuracy: evaluated in float64 it moves by cosine 0.984 .. 0.987 on the score path (tests/diag/fp32_vs_fp64.py) --
+            # fp32 summation noise flips a few 1e-5 of the 4-bit head-quantiser decisions and every flip moves a whole
+            # attention row (tests/diag/forward_flips.py).
+            c32, l32 = rep["grads"][n]["cos"], rep["grads"][n]["l2"]
+            ok = (c32 >= 0.985 and l32 <= 0.18 and cos >= 0.985 and l2 <= 0.18) if score else \
+                 (c32 >= 0.99 and l32 <= 0.12 and cos >= 0.99 and l2 <= 0.12)
+        else:
+            # A/B modes (OQ_WIDE=0 / OQ_GRID_ATTN=0 / OQ_INT_FPROP=0): bf16 tensors in front of 4-bit decisions decorrelate the
+            # quantisation-residue gradients from an fp32 run by precision mode; the bar is held against the storage model only
+            if score:
+                ok = cos >= 0.97 and l2 <= 0.25
+            elif "v_proj" in n or "out_smooth" in n:      # behind P @ V as well
+                ok = cos >= 0.98 and l2 <= 0.2
+            else:
+                ok = cos >= 0.995 and l2 <= 0.1
             c32 = rep["grads"][n]["cos"]
-            floor = 0.86 if any(t in n for t in ("q_proj", "k_proj", "qkt_smooth")) else (0.90 if ("v_proj" in n or "out_smooth" in n) else 0.975)
+            floor = 0.86 if score else (0.90 if ("v_proj" in n or "out_smooth" in n) else 0.975)
             if use_int and c32 < floor:
                 fails.append((n, "vs plain fp32", round(c32, 5), "floor", floor))
+        if not ok:
+            fails.append((n, round(cos, 5), round(l2, 4), round(rep["grads"][n]["cos"], 5), round(rep["grads"][n]["l2"], 4)))
     mods = {n: m for n, m in q.named_modules() if isinstance(m, QuantLinear)}
     for n, ref in ref_tw.items():
         got = mods[n].temp_weight.detach().float().cpu().numpy().astype(np.float64)
@@ -180,7 +185,7 @@ def test_production_step_vs_oracle(name):
         allrep = json.load(open(path)) if os.path.exists(path) else {}
         allrep[name] = rep
         json.dump(allrep, open(path, "w"), indent=1)
-    assert math.isfinite(loss) and rep["loss_rel"] <= 1e-2, rep["loss_rel"]
+    assert math.isfinite(loss) and rep["loss_rel"] <= (1.5e-3 if (wide or emu_grad is None) else 1e-2), rep["loss_rel"]
     if loss_e is not None:
         assert rep["loss_rel_bf16_model"] <= 1e-2, rep["loss_rel_bf16_model"]
         worst = min((v["cos_bf16_model"], k) for k, v in rep["grads"].items())
