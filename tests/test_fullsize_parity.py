@@ -130,10 +130,23 @@ def test_production_step_vs_oracle(name):
         g, r = g.double().reshape(-1), r.double().reshape(-1)
         return float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-300)), float((g - r).norm() / (r.norm() + 1e-300))
 
+    # the same step evaluated in float64 (tests/diag/fp32_vs_fp64.py wrote the fixture from the oracle): how far the production
+    # step and the fp32 oracle step each are from it
+    f64 = None
+    f64_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_f64_llama7b_w4a4_t2048.npz")
+    if name == "llama-7b-w4a4-let" and T == 2048 and os.path.exists(f64_path):
+        f64 = np.load(f64_path)
+        rep["loss_rel_f64"] = abs(loss - float(f64["loss"])) / float(f64["loss"])
+        rep["oracle_fp32_loss_rel_f64"] = abs(float(loss_o) - float(f64["loss"])) / float(f64["loss"])
     for n, p in q.named_parameters():
         g = p.grad.detach().cpu()
         cos, l2 = cmp(g, ref_grad[n])
         rep["grads"][n] = {"cos": cos, "l2": l2, "norm_ref": float(ref_grad[n].norm())}
+        if f64 is not None:
+            r64 = torch.from_numpy(f64["grad." + n])
+            c64, l64 = cmp(g, r64)
+            o64, ol64 = cmp(ref_grad[n], r64)
+            rep["grads"][n].update({"cos_f64": c64, "l2_f64": l64, "oracle_fp32_vs_f64_cos": o64, "oracle_fp32_vs_f64_l2": ol64})
         if emu_grad is not None:
             cos, l2 = cmp(g, emu_grad[n])       # the bar is held against the bf16 storage model of the same step
             rep["grads"][n].update({"cos_bf16_model": cos, "l2_bf16_model": l2})
@@ -190,4 +203,14 @@ def test_production_step_vs_oracle(name):
         assert rep["loss_rel_bf16_model"] <= 1e-2, rep["loss_rel_bf16_model"]
         worst = min((v["cos_bf16_model"], k) for k, v in rep["grads"].items())
         print("vs bf16 storage model: worst cos", worst, "worst l2", max((v["l2_bf16_model"], k) for k, v in rep["grads"].items()))
+    if f64 is not None:
+        worst_hip = min((v["cos_f64"], k) for k, v in rep["grads"].items())
+        worst_o32 = min((v["oracle_fp32_vs_f64_cos"], k) for k, v in rep["grads"].items())
+        print("vs the float64 evaluation of the step: production", worst_hip, "| fp32 oracle", worst_o32)
+        if wide:
+            # the production step is as close to the float64 step as the reference's own fp32 arithmetic is (margin: the
+            # two distances are both made of a few hundred flipped 4-bit decisions)
+            for k, v in rep["grads"].items():
+                if v["cos_f64"] < v["oracle_fp32_vs_f64_cos"] - 0.01:
+                    fails.append((k, "vs float64", round(v["cos_f64"], 5), "fp32 oracle:", round(v["oracle_fp32_vs_f64_cos"], 5)))
     assert not fails, fails

@@ -299,18 +299,28 @@ def test_batched_forward_matches_per_sample_and_fused_attention_matches_unfused(
     d1 = (o2[1].float() - o1[0].float()).abs()
     assert int((d0 != 0).sum()) == 0 and int((d1 != 0).sum()) == 0 and bool(torch.isfinite(o2.float()).all())
     qa = build()
-    of, gf = run(qa, x[:1])
+    of, gf = run(qa, x[:1])                    # fused attention on the integer grid (the default)
+    os.environ["OQ_GRID_ATTN"] = "0"
+    try:
+        qv = build()
+        ov, gv = run(qv, x[:1])                # fused attention on bf16 values
+    finally:
+        del os.environ["OQ_GRID_ATTN"]
     os.environ["OQ_NO_FLASH"] = "1"
     try:
         qb = build()
-        ou, gu = run(qb, x[:1])
+        ou, gu = run(qb, x[:1])                # unfused kernels (bf16 values, bf16 scores)
     finally:
         del os.environ["OQ_NO_FLASH"]
     sc_o = float(ou.float().abs().max())
+    assert float((ov.float() - ou.float()).abs().max()) / sc_o < 3e-2
     assert float((of.float() - ou.float()).abs().max()) / sc_o < 3e-2
     for n in gu:
-        rel = float((gf[n] - gu[n]).norm()) / (float(gu[n].norm()) + 1e-20)      # bf16 rounding noise of two kernel chains
+        rel = float((gv[n] - gu[n]).norm()) / (float(gu[n].norm()) + 1e-20)      # bf16 rounding noise of two kernel chains
         assert rel < 0.1, (n, rel)
+        # the grid path rounds nothing in front of the 4-bit decisions the two others round at: a little further away
+        rel = float((gf[n] - gu[n]).norm()) / (float(gu[n].norm()) + 1e-20)
+        assert rel < 0.15, (n, rel)
 
 
 def test_calibration_is_bitwise_reproducible():
