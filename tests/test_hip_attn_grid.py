@@ -119,3 +119,28 @@ def test_rope_quant_grid_output_times_scale_is_the_value_output():
         assert torch.equal(coords, coords.round()) and float(coords.abs().max()) <= 15.0
         assert torch.equal(coords * scale[:, h0:h0 + n, None], y_val.view(rows, n, hd))
         h0 += n
+
+
+def test_grid_entry_points_refuse_bad_arguments():
+    """Error behaviour of the new entry points: an OQError with a message, nothing launched."""
+    from omniquant_amd import _capi as C
+    T, nh, hd = 128, 2, 128
+    q = torch.zeros(1, T, nh, hd, dtype=torch.bfloat16, device=DEV)
+    o = torch.empty_like(q)
+    lse = torch.empty(1, nh, T, dtype=torch.float32, device=DEV)
+    sc = torch.ones(T, nh, dtype=torch.float32, device=DEV)
+    with pytest.raises(C.OQError, match="stride"):
+        C.call("oq_attn_fwd_grid", C.ptr(q), C.ptr(q), C.ptr(q), C.fptr(sc), C.fptr(sc), C.fptr(sc), 1, C.ptr(o), None,
+               C.fptr(lse), 1, T, nh, nh, hd, 0.1, 1, C.stream())
+    with pytest.raises(C.OQError, match="head_dim"):
+        C.call("oq_attn_fwd_grid", C.ptr(q), C.ptr(q), C.ptr(q), C.fptr(sc), C.fptr(sc), C.fptr(sc), nh, C.ptr(o), None,
+               C.fptr(lse), 1, T, nh, nh, 64, 0.1, 1, C.stream())
+    with pytest.raises(C.OQError, match="null"):
+        C.call("oq_attn_fwd_grid", C.ptr(q), C.ptr(q), C.ptr(q), None, C.fptr(sc), C.fptr(sc), nh, C.ptr(o), None,
+               C.fptr(lse), 1, T, nh, nh, hd, 0.1, 1, C.stream())
+    pre = torch.zeros(T, 3 * nh * hd, dtype=torch.float32, device=DEV)
+    cs = torch.ones(T, hd, dtype=torch.float32, device=DEV)
+    ys = [torch.empty(T, nh * hd, dtype=torch.bfloat16, device=DEV) for _ in range(3)]
+    with pytest.raises(C.OQError, match="grid coordinates"):
+        C.call("oq_qkv_rope_quant_fwd", C.ptr(pre), C.dt(pre), T, T, nh, nh, nh, hd, C.fptr(cs), C.fptr(cs), 16,
+               C.ptr(ys[0]), C.ptr(ys[1]), C.ptr(ys[2]), C.dt(ys[0]), 1, None, None, None, None, C.stream())

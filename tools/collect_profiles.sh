@@ -33,17 +33,21 @@ python tools/microbench_gemm_i8.py > $out/r3_gemm_i8_microbench.txt 2>&1
 python tools/microbench_wgrad.py > $out/r3_wgrad_microbench.txt 2>&1
 for c in llama-7b-w4a4-aug llama-7b-w3a16g128 llama-2-13b-w4a4 llama-2-70b-w2a16g64 opt-125m-w4a16; do python bench.py --config $c --steps 256 --warmup 32 --no-cpu-baseline 2>/dev/null; done > $out/r3_bench_configs.jsonl
 {
-  for kv in "OQ_INT_FPROP 0 1" "OQ_GEMM_W256 0 1" "OQ_INT_PRE_F32_QKV 0 1" "OQ_INT_PRE_F32_MLP 0 1"; do
+  for kv in "OQ_INT_FPROP 0 1" "OQ_GEMM_W256 0 1" "OQ_INT_PRE_F32_QKV 0 1" "OQ_INT_PRE_F32_MLP 0 1" "OQ_GRID_ATTN 0 1" "OQ_WIDE 0 1"; do
     set -- $kv
     for rep in 1 2; do for v in $2 $3; do
       echo -n "llama-7b-w4a4 $1=$v : "; env $1=$v python bench.py --steps 512 --warmup 128 --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(round(d['value'],1), 'sample-steps/s', round(d['ms_per_step'],4), 'ms')"
     done; done
   done
+  for rep in 1 2; do for v in 0 1; do
+    echo -n "llama-7b-w4a4 OQ_WIDE=$v OQ_GRID_ATTN=$v : "; OQ_WIDE=$v OQ_GRID_ATTN=$v python bench.py --steps 512 --warmup 128 --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(round(d['value'],1), 'sample-steps/s', round(d['ms_per_step'],4), 'ms')"
+  done; done
   for c in llama-7b-w3a16g128 llama-2-70b-w2a16g64; do for v in 0 1; do
     echo -n "$c OQ_GROUPQ=$v : "; OQ_GROUPQ=$v python bench.py --config $c --steps 128 --warmup 32 --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print(round(d['value'],1), 'sample-steps/s')"
   done; done
 } > $out/r3_ab_same_box.txt 2>&1
 python tools/blaslt_ceiling.py > $out/r3_gemm_vs_hipblaslt.txt 2>&1
 python tools/soak.py 3 3 > $out/r3_soak.txt 2>&1
+python tests/diag/forward_flips.py 2048 > $out/r3_forward_flips_t2048.txt 2>&1
 ls -la $out | head -60
 cut -c1-400 $out/r3_bench_default.json
