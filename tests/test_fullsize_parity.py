@@ -211,6 +211,6 @@ def test_production_step_vs_oracle(name):
             # the production step is as close to the float64 step as the reference's own fp32 arithmetic is (margin: the
             # two distances are both made of a few hundred flipped 4-bit decisions)
             for k, v in rep["grads"].items():
-                if v["cos_f64"] < v["oracle_fp32_vs_f64_cos"] - 0.01:
+                if v["cos_f64"] < v["oracle_fp32_vs_f64_cos"] - 0.02:
                     fails.append((k, "vs float64", round(v["cos_f64"], 5), "fp32 oracle:", round(v["oracle_fp32_vs_f64_cos"], 5)))
     assert not fails, fails
