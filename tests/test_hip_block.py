@@ -558,3 +558,73 @@ def test_propagate_pass_runs_the_integer_fprop_on_folded_weights(monkeypatch):
     e_bf = float((outs["0"].cpu() - ref).norm() / ref.norm())
     print(f"propagate pass vs the fp32 oracle, relative L2: integer operands {e_int:.3e}, bf16 operands {e_bf:.3e}")
     assert torch.isfinite(outs["1"]).all() and e_int < 6e-2 and e_int <= e_bf * 1.05, (e_int, e_bf)
+
+
+def test_gqa_block_w4a4_production_step_on_the_integer_grid():
+    """A grouped-query LLaMA block (hidden 1024, 8 heads x 128 over 2 key-value heads, T 256) W4A4 --lwc in production mode
+    (GQA + --let is refused, as the reference dies on it): integer fprop on all seven linears, attention on the integer grid with
+    the key / value scales of the SHARED heads, fp32 side channels.  One hipGraph-replayed sample-step against the CPU oracle's
+    plain fp32 step and against its storage model: loss and every LWC gradient."""
+    from oracle import ref_cpu as R
+    from omniquant_amd import ops
+    from omniquant_amd import synthetic as S
+    from omniquant_amd.calibrate import StepRunner, decoder_layer_class, default_args
+    from omniquant_amd.optim import BlockOptimizer
+    H, Tn, nh, nkv = 1024, 256, 8, 2
+    cfg = S.make_config(None, family="llama", hidden_size=H, inter=2048, heads=nh, kv_heads=nkv)
+    layer = S.make_layer(cfg, seed=5, device="cpu")
+    weights = {n: p.detach().float() for n, p in layer.named_parameters()}
+    x = S.make_calib_inputs(1, Tn, H, dtype=torch.float32).to(torch.bfloat16).float()
+    mask, pos = S.causal_mask(Tn), torch.arange(Tn)[None]
+    cd = dict(hidden_size=H, num_attention_heads=nh, num_key_value_heads=nkv, rms_norm_eps=1e-6)
+
+    def oracle(**kw):
+        blk = R.Block("llama", cd, weights, R.QuantSpec(4, 4, None, True, False), max_pos=Tn)
+        with torch.no_grad():
+            tgt = blk.forward(x, mask, pos, None, False)
+        temps = blk.temporaries(**({"store_dtype": torch.bfloat16, "int_fprop": True} if kw else {}))
+        out = blk.forward(x, mask, pos, temps=temps, act_quant=True, **kw)
+        loss = torch.nn.functional.mse_loss(tgt.to(torch.bfloat16).float() if kw else tgt, out)
+        loss.backward()
+        return tgt, float(loss.detach()), {n: p.grad.detach().clone() for n, p in blk.params.items()}
+
+    tgt, loss32, g32 = oracle()
+    _, loss_m, g_m = oracle(act_dtype=torch.bfloat16, int_fprop=True, wide=True)
+    args = default_args(wbits=4, abits=4, lwc=True, let=False, net="llama", nsamples=1)
+    q = decoder_layer_class("llama")(cfg, S.make_layer(cfg, seed=5, device=DEV), args).to(DEV)
+    q.compute_dtype = torch.bfloat16
+    q.set_quant_state(False, True)
+    q.let = False
+    opt = BlockOptimizer(q, args.let_lr, args.lwc_lr, args.wd)
+    opt.clear_grads_in_step = False
+    calls = {"grid": 0, "i8": 0}
+    o_attn, o_i8 = ops.FusedCausalAttnFn, ops.gemm_i8
+
+    class _Spy:
+        @staticmethod
+        def apply(*a):
+            calls["grid"] += int(len(a) > 4 and a[4] is not None)
+            return o_attn.apply(*a)
+
+    def spy_i8(*a, **k):
+        calls["i8"] += 1
+        return o_i8(*a, **k)
+    ops.FusedCausalAttnFn, ops.gemm_i8 = _Spy, spy_i8
+    try:
+        runner = StepRunner(q, opt, mask.to(DEV), pos.to(DEV), (1, Tn, H), torch.bfloat16, False, True, use_graph=True)
+        runner.run(x.to(DEV).to(torch.bfloat16), tgt.to(DEV).to(torch.bfloat16))
+    finally:
+        ops.FusedCausalAttnFn, ops.gemm_i8 = o_attn, o_i8
+    torch.cuda.synchronize()
+    assert calls["grid"] >= 1 and calls["i8"] >= 4, calls          # (warm-up + capture: each forward has 1 + 4 of them)
+    loss = float(runner.loss)
+    assert abs(loss - loss32) <= 3e-3 * loss32 and abs(loss - loss_m) <= 3e-3 * loss_m, (loss, loss32, loss_m)
+    worst = {}
+    for n, p in q.named_parameters():
+        g = p.grad.detach().double().cpu().reshape(-1)
+        for tag, ref in (("fp32", g32[n]), ("model", g_m[n])):
+            r = ref.double().reshape(-1)
+            c = float(torch.dot(g, r) / (g.norm() * r.norm() + 1e-300))
+            worst[tag] = min(worst.get(tag, (2.0, "")), (c, n))
+    print("worst gradient cosine vs plain fp32 / vs storage model:", worst)
+    assert worst["fp32"][0] >= 0.99 and worst["model"][0] >= 0.999, worst          # measured 0.9983 / 0.99998
