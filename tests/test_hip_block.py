@@ -570,6 +570,8 @@ def test_gqa_block_w4a4_production_step_on_the_integer_grid():
     from omniquant_amd import synthetic as S
     from omniquant_amd.calibrate import StepRunner, decoder_layer_class, default_args
     from omniquant_amd.optim import BlockOptimizer
+    if not (ops.wide_on() and ops.grid_attention_on() and ops.int_fprop_on()):
+        pytest.skip("A/B switches put 16-bit tensors back: this test is about the default production mode")
     H, Tn, nh, nkv = 1024, 256, 8, 2
     cfg = S.make_config(None, family="llama", hidden_size=H, inter=2048, heads=nh, kv_heads=nkv)
     layer = S.make_layer(cfg, seed=5, device="cpu")
