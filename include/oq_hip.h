@@ -152,6 +152,17 @@ int oq_gemm_i8(const void* a_codes, const void* b_codes, void* c, float* c_wide,
                int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                int a_bits, int b_bits, int out_dtype, void* stream);
 
+/* The weight-gradient products of one backward pass, dW_i[N_i][K_i] = dY_i[T][N_i]^T X_i[T][K_i] (autograd of F.linear at
+ * quantize/int_linear.py:62, bf16), as ONE launch of the 256x256x32 kernel: separate launches each end in a partial round of
+ * the CUs, together their tiles fill whole rounds (LLaMA-7B: 12.06 rounds instead of 3 + 6 + 1 + 3; when the excess is a
+ * single tile row / column of one item -- here 16 tiles of down_proj -- that strip is computed with a split contraction:
+ * fp32 partials in `workspace` (oq_wgrad_group_workspace bytes, may be NULL: no peeling), fixed-order reduce).  Results equal
+ * those of n oq_gemm calls bit for bit outside a peeled strip, to fp32 summation order inside it.  Items that do not fit the
+ * kernel (ragged shapes, < 256 rows / columns) make the call fall back to n single launches.  `items`: array of n structs
+ * { const void* gy; const void* x; void* gw; int64_t N, K, T, ld_gy, ld_x, ld_gw; }. */
+int64_t oq_wgrad_group_workspace(const void* items, int n);
+int oq_wgrad_group(const void* items, int n, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* column sums: out[n] = sum_m x[m,n]  (bias gradients).  out f32, overwritten.  Deterministic (slab partials in the
  * workspace, added in slab order; no atomics).  cols % 8 == 0. */
 int64_t oq_colsum_workspace(int64_t rows, int64_t cols);

@@ -27,6 +27,7 @@ SIGNATURES = {
     "oq_gemm_ws": [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                 _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp, _i64, _vp],
     "oq_gemm_i8": [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp],
+    "oq_wgrad_group": [_vp, _i32, _vp, _i64, _vp],
     "oq_colsum": [_vp, _i32, _i64, _i64, _vp, _vp, _i64, _vp],
     "oq_norm_fwd": [_vp, _i32, _i64, _i64, _vp, _vp, _f32, _i32, _vp, _vp, _vp, _vp],
     "oq_norm_bwd": [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i64, _vp],
@@ -81,6 +82,12 @@ class FakeQuantFwdArgs(ctypes.Structure):
                 ("wshift", _vp), ("codes", _vp), ("csum", _vp)]
 
 
+class WgradItem(ctypes.Structure):
+    """item of oq_wgrad_group (include/oq_hip.h): gw[N][K] = gy[T][N]^T x[T][K]."""
+    _fields_ = [("gy", _vp), ("x", _vp), ("gw", _vp), ("N", _i64), ("K", _i64), ("T", _i64), ("ld_gy", _i64), ("ld_x", _i64),
+                ("ld_gw", _i64)]
+
+
 class FakeQuantBwdArgs(ctypes.Structure):
     """oq_fakequant_bwd_args of include/oq_hip.h."""
     _fields_ = [("w", _vp), ("w_dtype", _i32), ("rows", _i64), ("cols", _i64), ("seg", _i64), ("nbits", _i32),
@@ -95,7 +102,7 @@ SIGNATURES["oq_fakequant_bwd_multi"] = [_vp, _i32, _vp]
 
 # functions returning a size instead of an error code
 SIZE_FUNCS = {"oq_fakequant_bwd_workspace": [_i64, _i64], "oq_norm_bwd_workspace": [_i64, _i64],
-              "oq_attn_supported": [_i32, _i64, _i32, _i32], "oq_act_stats_workspace": [_i64, _i64],
+              "oq_attn_supported": [_i32, _i64, _i32, _i32], "oq_wgrad_group_workspace": [_vp, _i32], "oq_act_stats_workspace": [_i64, _i64],
               "oq_colsum_workspace": [_i64, _i64], "oq_gemm_workspace": [_i64, _i64, _i64, _i32, _i64, _i32], "oq_rope_quant_supported": [_i32, _i32],
               "oq_norm_quant_supported": [_i32, _i64], "oq_norm_quant_bwd_workspace": [_i64, _i64],
               "oq_fakequant_codes_supported": [_i64, _i64, _i32, _i32]}

@@ -137,7 +137,12 @@ class StepRunner:
         C.call("oq_mse_fwd_bwd", C.ptr(src), C.dt(src), C.ptr(self.t1), C.ptr(self.t2), C.dt(out), out.numel(), 1.0,
                C.fptr(self._loss_buf), C.ptr(g), C.stream())
         self.opt.zero_grad(lazy=True)       # a no-op once the fused optimiser step clears the arena behind each update
-        out.backward(g)
+        ops.WgradQueue.enabled = True       # the block's weight-gradient GEMMs run as one grouped launch when the pass ends
+        try:
+            out.backward(g)
+        finally:
+            ops.WgradQueue.enabled = False
+        ops.WeightQuantBatch.flush_pending()        # (normally done by the engine callbacks already)
         self.opt.step()
 
     def _capture(self):

@@ -702,17 +702,17 @@ constexpr int W2_NSTAGE = 4;
 constexpr int W2_EPI_RS = 272;                     // bytes per parked row (64 fp32 + pad)
 constexpr int W2_LDS = (W2_NSTAGE * W2_STAGE > 8 * 64 * W2_EPI_RS) ? W2_NSTAGE * W2_STAGE : 8 * 64 * W2_EPI_RS;
 
+// XCD-aware bijective remap of the linear workgroup id (same formula as the other kernels)
+__device__ __forceinline__ int w256_tile_id() {
+    const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
 template <typename TOUT>
-__global__ void __launch_bounds__(512) gemm_bf16_w256_kernel(GemmP p) {
-    __shared__ __attribute__((aligned(16))) char smem[W2_LDS];
+__device__ __forceinline__ void w256_body(const GemmP& p, const int tile, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 1, wn = wid & 1;              // wave tile: rows wm*64 .. +64, columns wn*128 .. +128
-    int tile;
-    {
-        const int nwg = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    }
     int64_t m0, n0;
     {
         const int W = p.blk48 > 0 ? p.blk48 : 8;        // strip-ordered ids, as in gemm_bf16_p3_kernel
@@ -863,6 +863,38 @@ __global__ void __launch_bounds__(512) gemm_bf16_w256_kernel(GemmP p) {
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the second half re-uses the wave's parking region
     }
+}
+
+template <typename TOUT>
+__global__ void __launch_bounds__(512) gemm_bf16_w256_kernel(GemmP p) {
+    __shared__ __attribute__((aligned(16))) char smem[W2_LDS];
+    w256_body<TOUT>(p, w256_tile_id(), smem);
+}
+
+// Several weight-gradient problems (same kernel, same tile time: K = tokens for all of them) in ONE launch: workgroup ids
+// [start[i], start[i+1]) belong to problem i.  Separate launches each end in a partial round of the 256 CUs; together the
+// tiles of a LLaMA-7B step's four wgrads make 12.06 rounds instead of 3 + 6 + 1 + 3 = 13 (the host peels the last 16 tiles off
+// and runs them with a split contraction, oq_wgrad_group), LLaMA-2-13B's 18.9 instead of 21.
+struct GemmGroupP {
+    GemmP p[4];
+    int start[5];
+    int n;
+};
+
+template <typename TOUT>
+__global__ void __launch_bounds__(512) gemm_bf16_w256_group_kernel(GemmGroupP g) {
+    __shared__ __attribute__((aligned(16))) char smem[W2_LDS];
+    int tile = w256_tile_id();
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < g.n && tile >= g.start[i]) gi = i;
+    tile -= g.start[gi];
+    GemmP p = g.p[0];                   // (wave-uniform: scalar registers)
+    if (gi == 1) p = g.p[1];
+    else if (gi == 2) p = g.p[2];
+    else if (gi == 3) p = g.p[3];
+    w256_body<TOUT>(p, tile, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1444,5 +1476,153 @@ static int oq_gemm_impl(const void* a, const void* bm, void* c, const float* bia
         return OQ_E_UNSUPPORTED;
     }
     OQ_CHECK_LAUNCH("oq_gemm");
+    return OQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The weight-gradient products of one backward pass as ONE launch of the 256x256x32 kernel (gemm_bf16_w256_group_kernel).
+// item i: gw[N_i][K_i] = gy_i[T][N_i]^T x_i[T][K_i]  (bf16, both operands k-strided, no bias / addend).
+// If the tiles of all items exceed a whole number of rounds of the CUs by a few tiles (<= a quarter round) and one item has a
+// tile row / column of exactly that many tiles, that strip is peeled off and computed with a split contraction (256x128x64
+// kernel, fp32 partials in `workspace`, fixed-order reduce): a quarter-length tail instead of a whole extra round.
+// ---------------------------------------------------------------------------------------------------
+struct OqWgradItem {
+    const void* gy;
+    const void* x;
+    void* gw;
+    int64_t N, K, T, ld_gy, ld_x, ld_gw;
+};
+
+static int wgrad_n_cu() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
+
+static bool wgrad_item_groupable(const OqWgradItem& it) {
+    return it.gy && it.x && it.gw && it.N >= 256 && it.K >= 256 && it.T >= 64 && it.T % W2_BK == 0 && it.N % 8 == 0 && it.K % 8 == 0 &&
+           it.ld_gy % 8 == 0 && it.ld_x % 8 == 0 && it.ld_gw % 8 == 0 && oq_aligned16(it.gy) && oq_aligned16(it.x) && oq_aligned16(it.gw);
+}
+
+extern "C" int64_t oq_wgrad_group_workspace(const void* items_, int n) {
+    // bytes the peeled strip's split contraction may need: 8 parts x (256 x the longest side) fp32
+    const OqWgradItem* items = reinterpret_cast<const OqWgradItem*>(items_);
+    int64_t mx = 0;
+    for (int i = 0; i < n; ++i) {
+        mx = items[i].N > mx ? items[i].N : mx;
+        mx = items[i].K > mx ? items[i].K : mx;
+    }
+    return 8 * 256 * mx * 4;
+}
+
+extern "C" int oq_wgrad_group(const void* items_, int n, void* workspace, int64_t workspace_bytes, void* stream) {
+    const OqWgradItem* items = reinterpret_cast<const OqWgradItem*>(items_);
+    OQ_CHECK_ARG(items && n > 0 && n <= 16, "oq_wgrad_group: %d items (1 .. 16)", n);
+    hipStream_t st = (hipStream_t)stream;
+    auto single = [&](const OqWgradItem& it) {
+        return oq_gemm_impl(it.gy, it.x, it.gw, nullptr, nullptr, it.N, it.K, it.T, it.ld_gy, it.ld_x, it.ld_gw, 0, 0, OQ_BF16, OQ_BF16,
+                            1.0f, 1, 1, 0, 0, 0, 0, 0, 0, 0, stream);
+    };
+    bool ok = dbg_env_i("OQ_WGRAD_GROUP", 1) != 0 && n >= 2;
+    for (int i = 0; i < n && ok; ++i) ok = wgrad_item_groupable(items[i]);
+    if (!ok) {
+        for (int i = 0; i < n; ++i)
+            if (int rc = single(items[i])) return rc;
+        return OQ_OK;
+    }
+    for (int base = 0; base < n; base += 4) {
+        const int cnt = n - base < 4 ? n - base : 4;
+        if (cnt == 1) {
+            if (int rc = single(items[base])) return rc;
+            continue;
+        }
+        OqWgradItem it[4];
+        int64_t tm[4], tn[4], total = 0;
+        for (int i = 0; i < cnt; ++i) {
+            it[i] = items[base + i];
+            tm[i] = (it[i].N + W2_BM - 1) / W2_BM;
+            tn[i] = (it[i].K + W2_BN - 1) / W2_BN;
+            total += tm[i] * tn[i];
+        }
+        // ---- peel a strip so that the rest is a whole number of rounds ----
+        const int ncu = wgrad_n_cu();
+        const int64_t rem = total % ncu;
+        int peel_i = -1, peel_rows = 0, peel_cols = 0;       // tile rows (of gw) or tile columns taken off item peel_i
+        if (rem != 0 && rem <= ncu / 4 && dbg_env_i("OQ_WGRAD_PEEL", 1) != 0 && workspace) {
+            for (int i = cnt - 1; i >= 0 && peel_i < 0; --i) {
+                if (it[i].N % W2_BM != 0 || it[i].K % W2_BN != 0) continue;
+                if (rem % tm[i] == 0 && rem / tm[i] < tn[i]) { peel_i = i; peel_cols = (int)(rem / tm[i]); }
+                else if (rem % tn[i] == 0 && rem / tn[i] < tm[i]) { peel_i = i; peel_rows = (int)(rem / tn[i]); }
+            }
+        }
+        OqWgradItem strip{};
+        int strip_parts = 1;
+        if (peel_i >= 0) {
+            strip = it[peel_i];
+            const int64_t es = 2;
+            if (peel_cols) {            // the last peel_cols * 256 columns of gw (= columns of x)
+                const int64_t c0 = it[peel_i].K - (int64_t)peel_cols * W2_BN;
+                strip.x = (const char*)it[peel_i].x + c0 * es;
+                strip.gw = (char*)it[peel_i].gw + c0 * es;
+                strip.K = (int64_t)peel_cols * W2_BN;
+                it[peel_i].K = c0;
+                tn[peel_i] -= peel_cols;
+            } else {                    // the last peel_rows * 256 rows of gw (= columns of gy)
+                const int64_t r0 = it[peel_i].N - (int64_t)peel_rows * W2_BM;
+                strip.gy = (const char*)it[peel_i].gy + r0 * es;
+                strip.gw = (char*)it[peel_i].gw + r0 * it[peel_i].ld_gw * es;
+                strip.N = (int64_t)peel_rows * W2_BM;
+                it[peel_i].N = r0;
+                tm[peel_i] -= peel_rows;
+            }
+            // split contraction of the strip: S parts so that S x (256x128 tiles) fill about one round
+            const int64_t tiles3 = ((strip.N + P3_BM - 1) / P3_BM) * ((strip.K + P3_BN - 1) / P3_BN);
+            int S = 1;
+            for (int s = 8; s >= 2; s /= 2)
+                if (strip.T % (s * BK) == 0 && strip.T / s >= 256 && tiles3 * s <= ncu && (int64_t)s * strip.N * strip.K * 4 <= workspace_bytes) { S = s; break; }
+            if (S < 2 || !oq_aligned16(workspace) || !oq_aligned16(strip.gw) || !oq_aligned16(strip.x) || !oq_aligned16(strip.gy)) {
+                // cannot split: undo the peel
+                it[peel_i] = items[base + peel_i];
+                tm[peel_i] = (it[peel_i].N + W2_BM - 1) / W2_BM;
+                tn[peel_i] = (it[peel_i].K + W2_BN - 1) / W2_BN;
+                peel_i = -1;
+            } else {
+                strip_parts = S;
+            }
+        }
+        GemmGroupP g{};
+        g.n = cnt;
+        int64_t start = 0;
+        for (int i = 0; i < cnt; ++i) {
+            GemmP& p = g.p[i];
+            p.a = it[i].gy; p.b = it[i].x; p.c = it[i].gw;
+            p.M = it[i].N; p.N = it[i].K; p.K = it[i].T; p.lda = it[i].ld_gy; p.ldb = it[i].ld_x; p.ldc = it[i].ld_gw;
+            p.alpha = 1.0f; p.batch_i = 1; p.tiles_m = (int)tm[i]; p.tiles_n = (int)tn[i]; p.blk48 = 8; p.epi_lds = 1;
+            g.start[i] = (int)start;
+            start += tm[i] * tn[i];
+        }
+        g.start[cnt] = (int)start;
+        OQ_CHECK_ARG(start > 0 && start < (1ll << 30), "oq_wgrad_group: %lld tiles", (long long)start);
+        hipLaunchKernelGGL((gemm_bf16_w256_group_kernel<bf16_t>), dim3((unsigned)start), dim3(512), 0, st, g);
+        OQ_CHECK_LAUNCH("oq_wgrad_group");
+        if (peel_i >= 0) {
+            const int S = strip_parts;
+            g_splitk_request = S;
+            const int rc = oq_gemm_impl(strip.gy, strip.x, workspace, nullptr, nullptr, strip.N, strip.K, strip.T, strip.ld_gy, strip.ld_x,
+                                        strip.K, 0, 0, OQ_BF16, OQ_F32, 1.0f, 1, 1, 0, 0, 0, 0, 0, 0, 0, stream);
+            g_splitk_request = 1;
+            if (rc != OQ_OK) return rc;
+            const int64_t nvec = strip.N * (strip.K / 8);
+            const unsigned grid = (unsigned)(nvec / 256 + 1 < 4096 ? nvec / 256 + 1 : 4096);
+            hipLaunchKernelGGL((splitk_reduce_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)workspace, S, strip.N, strip.K,
+                               (bf16_t*)strip.gw, strip.ld_gw, nullptr, (const bf16_t*)nullptr, 1.0f);
+            OQ_CHECK_LAUNCH("oq_wgrad_group(reduce)");
+        }
+    }
     return OQ_OK;
 }

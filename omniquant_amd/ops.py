@@ -29,6 +29,85 @@ def _f32(t):
 # ------------------------------------------------------------------------------------------------------
 # UniformAffineQuantizer core (+ LET weight re-parameterisation)
 # ------------------------------------------------------------------------------------------------------
+class WgradQueue:
+    """Deferred weight-gradient GEMMs of one backward pass.  The four wgrads of a block (q | k | v, o, gate | up, down) are
+    independent of the rest of the backward chain -- only the weight quantisers' backward reads them -- so, when `enabled` (the
+    calibration step sets it), the Linear nodes park them here and they run as ONE grouped launch when the backward pass ends
+    (oq_wgrad_group: the tiles of all of them fill whole rounds of the CUs instead of four ragged last rounds).  A consumer that
+    meets a parked gradient (`pending(t)`) either parks its own launch behind the group (`after`) or calls `flush()` first.
+    Only weights that come out of FakeQuantFn (`_oq_fq_out`) are parked: its backward knows the protocol.
+    OFF by default (OQ_WGRAD_GROUP=1 switches it on): measured same-box, LLaMA-2-13B gains 0.55 % (gate | up + o_proj = exactly
+    10 rounds instead of 9 + 2) and LLaMA-7B loses 0.7 % -- its 2064 tiles of down_proj + gate | up are 8 rounds + 16 tiles, the
+    peeled strip costs 31 us of the 53 us round it saves, the mixed launch runs 4 % slower per round, and a parked gradient
+    reaches its weight quantiser's backward from HBM instead of the Infinity Cache."""
+    enabled = False
+    items = []        # (gy2, x2, gw, N, K, T, ld_gy, ld_x, ld_gw, gy_off)
+    ranges = []       # [lo, hi) device addresses of the parked outputs
+    after = []        # (entry point, args, keep-alive) launches that read parked outputs
+
+    @staticmethod
+    def on():
+        return WgradQueue.enabled and os.environ.get("OQ_WGRAD_GROUP", "0") != "0"
+
+    @staticmethod
+    def park(gy2, x2, gw, N, K, T, ld_gy, ld_x, ld_gw, gy_off=0):
+        if not WgradQueue.items and not WgradQueue.after:
+            torch.autograd.Variable._execution_engine.queue_callback(WgradQueue.flush)
+        WgradQueue.items.append((gy2, x2, gw, int(N), int(K), int(T), int(ld_gy), int(ld_x), int(ld_gw), int(gy_off)))
+        WgradQueue.ranges.append((gw.data_ptr(), gw.data_ptr() + gw.numel() * gw.element_size()))
+        # Launch as soon as the parked tiles make (nearly) whole rounds of the CUs: a gradient that waits longer than it must
+        # is read by its weight quantiser's backward from HBM instead of from the Infinity Cache (measured: parking all four
+        # until the pass ends loses what the fuller rounds gain).  LLaMA-7B: down_proj (688 tiles) waits for gate | up (1376):
+        # 2064 = 8 rounds + one tile column; o_proj (256) and q | k | v (768) are whole rounds and go at once.
+        tiles = sum(-(-it[3] // 256) * -(-it[4] // 256) for it in WgradQueue.items)
+        rem = tiles % _n_cus()
+        if rem == 0 or rem <= _n_cus() // 4:
+            WgradQueue.flush()
+
+    @staticmethod
+    def pending(t):
+        if t is None or not WgradQueue.ranges:
+            return False
+        p = t.data_ptr()
+        return any(lo <= p < hi for lo, hi in WgradQueue.ranges)
+
+    @staticmethod
+    def flush():
+        items, after = WgradQueue.items, WgradQueue.after
+        WgradQueue.items, WgradQueue.after, WgradQueue.ranges = [], [], []
+        if items:
+            arr = (C.WgradItem * len(items))()
+            for i, (gy2, x2, gw, N, K, T, ld_gy, ld_x, ld_gw, off) in enumerate(items):
+                arr[i] = C.WgradItem(gy2.data_ptr() + off * gy2.element_size(), x2.data_ptr(), gw.data_ptr(), N, K, T, ld_gy, ld_x, ld_gw)
+            ws_bytes = C.size_call("oq_wgrad_group_workspace", ctypes.addressof(arr), len(items))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=items[0][2].device)
+            C.call("oq_wgrad_group", ctypes.addressof(arr), len(items), ws.data_ptr(), ws_bytes, C.stream())
+        for name, args, _keep in after:
+            C.call(name, *args, C.stream())
+
+    @staticmethod
+    def drop():
+        WgradQueue.items, WgradQueue.after, WgradQueue.ranges = [], [], []
+
+
+_N_CUS = [0]
+
+
+def _n_cus():
+    if not _N_CUS[0]:
+        _N_CUS[0] = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count) or 256
+    return _N_CUS[0]
+
+
+def wgrad(gy2, x2, gw, N, K, T, ld_gy, ld_x, ld_gw, gy_off=0, park=False):
+    """gw[N, K] = gy2[T, gy_off : gy_off + N]^T @ x2[T, K] (both operands k-strided); parked in the WgradQueue when the caller
+    allows it (the weight came out of FakeQuantFn) and a calibration step is collecting them."""
+    if park and WgradQueue.on() and gw.dtype == torch.bfloat16 and gy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16:
+        WgradQueue.park(gy2, x2, gw, N, K, T, ld_gy, ld_x, ld_gw, gy_off)
+    else:
+        gemm(gy2, x2, gw, N, K, T, ld_gy, ld_x, ld_gw, False, False, a_off=gy_off)
+
+
 class WeightQuantBatch:
     """`with WeightQuantBatch():` -- the FakeQuantFn calls made inside (the LET weights of one shape: q, k, v, o) are launched
     as ONE multi-matrix kernel when the block ends (oq_fakequant_fwd_multi), and their backward calls as one launch plus one
@@ -85,7 +164,7 @@ class WeightQuantBatch:
             torch.autograd.Variable._execution_engine.queue_callback(WeightQuantBatch.flush_pending)
         self.bwd.append(args)
         self.keep.append(keep)
-        if len(self.bwd) == self.n:
+        if len(self.bwd) == self.n and not WgradQueue.items:      # (parked weight gradients: wait for flush_pending)
             self.flush_backward()
 
     def flush_backward(self):
@@ -106,6 +185,7 @@ class WeightQuantBatch:
 
     @staticmethod
     def flush_pending():
+        WgradQueue.flush()              # parked weight gradients first: the launches below read them
         for b in list(WeightQuantBatch.pending):
             b.flush_backward()
 
@@ -117,6 +197,7 @@ class WeightQuantBatch:
             b.bwd, b.keep = [], []
         WeightQuantBatch.pending = []
         WeightQuantBatch.active = None
+        WgradQueue.drop()
 
 
 class FakeQuantFn(torch.autograd.Function):
@@ -242,11 +323,16 @@ class FakeQuantFn(torch.autograd.Function):
                  C.fptr(g_cm), C.fptr(g_sh), C.fptr(g_rd), C.fptr(g_rm), C.fptr(ws), ws_n)
         routed = all(r is not None for r, t in zip((r_cm, r_rd, r_rm, r_sh, r_up, r_low), (g_cm, g_rd, g_rm, g_sh, g_up, g_low))
                      if t is not None)
+        keep = (w, cm, rd, rm, sh, u, l, xmin, xmax, gy, gws, g_up, g_low, g_cm, g_sh, g_rd, g_rm, ws)
         if ctx.batch is not None and gx is None and routed:
             # deferred only when no gradient goes back to autograd (AccumulateGrad would copy a buffer that is not filled yet):
             # every consumer (the optimiser arena, optim.GradCollector.flush) runs after the batch is flushed
-            ctx.batch.add_backward(bargs, (w, cm, rd, rm, sh, u, l, xmin, xmax, gy, gws, g_up, g_low, g_cm, g_sh, g_rd, g_rm, ws))
+            ctx.batch.add_backward(bargs, keep)
+        elif WgradQueue.pending(gy) and gx is None and routed:
+            WgradQueue.after.append(("oq_fakequant_bwd", bargs, keep))      # dW is parked: this launch goes right behind the group
         else:
+            if WgradQueue.pending(gy):
+                WgradQueue.flush()
             C.call("oq_fakequant_bwd", *bargs, C.stream())
         if gx is not None and gx.dtype != ctx.in_dtype:
             gx = gx.to(ctx.in_dtype)
@@ -496,6 +582,7 @@ class LinearFn(torch.autograd.Function):
         """stash (dict): with "want_wide" the integer fprop also writes its un-rounded float32 result into stash["wide"] (the
         returned bf16 tensor is its rounded copy), and the residual is read from stash["res_wide"] (float32) when given."""
         ctx.sib = sib
+        ctx.park_wgrad = bool(getattr(wq, "_oq_fq_out", False))       # the weight's producer knows the WgradQueue protocol
         x2 = x.contiguous().view(-1, x.shape[-1])
         wq = wq.contiguous()
         T, K = x2.shape
@@ -544,7 +631,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.empty((N, K), dtype=wq.dtype, device=x2.device)
             # dW[n,k] = sum_t dY[t,n] * X[t,k]   (both operands k-strided)
-            gemm(gy2, x2, gw, N, K, T, N, K, K, False, False)
+            wgrad(gy2, x2, gw, N, K, T, N, K, K, park=ctx.park_wgrad)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.empty((N,), dtype=torch.float32, device=x2.device)
             ws_n = C.size_call("oq_colsum_workspace", T, N)
@@ -648,6 +735,7 @@ class QKVRopeQuantFn(torch.autograd.Function):
             if w.dtype != x2.dtype:
                 raise C.OQError(f"QKVRopeQuantFn: weight dtype {w.dtype} != activation dtype {x2.dtype}")
         offs = [0, Ns[0], Ns[0] + Ns[1]]
+        ctx.park_wgrad = all(getattr(w, "_oq_fq_out", False) for w in (wq, wk, wv))
         wall = stacked_rows(ws)
         ball = stacked_vectors(bs_) if wall is not None else False
         ctx.stacked = wall is not None and ball is not False
@@ -745,13 +833,13 @@ class QKVRopeQuantFn(torch.autograd.Function):
         if wall is not None and need[1] and need[3] and need[5]:
             # dW of the three as row blocks of one buffer: ONE GEMM with M = Nq + Nk + Nv
             gwall = torch.empty((Ntot, K), dtype=wall.dtype, device=x2.device)
-            gemm(gpre, x2, gwall, Ntot, K, rows, Ntot, K, K, False, False)
+            wgrad(gpre, x2, gwall, Ntot, K, rows, Ntot, K, K, park=ctx.park_wgrad)
             gws = [gwall[off:off + N] for N, off in zip(Ns, offs)]
         else:
             for i, (w, N, off) in enumerate(zip(ws, Ns, offs)):
                 if need[1 + 2 * i]:
                     gws[i] = torch.empty((N, K), dtype=w.dtype, device=x2.device)
-                    gemm(gpre, x2, gws[i], N, K, rows, Ntot, K, K, False, False, a_off=off)
+                    wgrad(gpre, x2, gws[i], N, K, rows, Ntot, K, K, gy_off=off, park=ctx.park_wgrad)
         gbs = [None, None, None]
         if any(has_bias[i] and need[2 + 2 * i] for i in range(3)):
             gb = torch.empty((Ntot,), dtype=torch.float32, device=x2.device)
@@ -1118,6 +1206,7 @@ class StackedGateUpFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wg, bg, wu, bu, nbits, stash, sib=None, xint=None, wints=None):
         ctx.sib = sib
+        ctx.park_wgrad = bool(getattr(wg, "_oq_fq_out", False) and getattr(wu, "_oq_fq_out", False))
         x2 = x.contiguous().view(-1, x.shape[-1])
         rows, K = x2.shape
         wall = stacked_rows([wg, wu])
@@ -1190,7 +1279,7 @@ class StackedGateUpFn(torch.autograd.Function):
                 gx = ctx.sib.offer(gx)
         if need[1] or need[3]:
             gwall = torch.empty((2 * I, K), dtype=wall.dtype, device=x2.device)
-            gemm(gpre, x2, gwall, 2 * I, K, rows, 2 * I, K, K, False, False)
+            wgrad(gpre, x2, gwall, 2 * I, K, rows, 2 * I, K, K, park=ctx.park_wgrad)
             gwg, gwu = (gwall[:I] if need[1] else None), (gwall[I:] if need[3] else None)
         if has_bias and (need[2] or need[4]):
             gb = torch.empty((2 * I,), dtype=torch.float32, device=x2.device)

@@ -100,6 +100,7 @@ class UniformAffineQuantizer(nn.Module):
         res = ops.fake_quant(x, self.n_bits, seg, up, low, self.symmetric, out_dtype, stash,
                              col_mul, row_div, row_mul, shift, out=out, src=src)
         self.scale, self.round_zero_point = stash["scale"], stash["zp"]
+        (res[0] if isinstance(res, tuple) else res)._oq_fq_out = True      # its backward knows ops.WgradQueue's protocol
         ic = stash.get("int")
         if ic is not None:
             self.int_codes = ic

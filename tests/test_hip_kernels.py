@@ -1283,3 +1283,50 @@ def test_groupq_kernels_match_segment_kernels(monkeypatch, rows, cols, seg, nbit
     for a, b in ((gu0, gu1), (gl0, gl1)):
         d = (a[ok] - b[ok]).abs().max()
         assert float(d) <= 2e-5 * float(a[ok].abs().max()) + 1e-12, float(d)
+
+
+@pytest.mark.parametrize("shapes", [
+    # (N, K) of each dW; T = tokens.  7B: 3088 tiles of 256x256 = 12 rounds + 16 -> one tile column of down_proj is peeled
+    [(12288, 4096), (4096, 4096), (22016, 4096), (4096, 11008)],
+    [(1024, 512), (512, 512), (768, 1024)],                     # small: no peel (rem too large), 3 items
+    [(4096, 4096), (200, 512)],                                 # an item the kernel does not take (< 256 rows): single launches
+])
+def test_wgrad_group_equals_single_launches(shapes):
+    """oq_wgrad_group (all weight gradients of a backward pass in one launch of the 256x256x32 kernel, a peeled strip with a split
+    contraction) vs one oq_gemm per item: bit-identical outside the peeled strip, fp32-summation-order close inside it."""
+    import ctypes
+    from omniquant_amd import ops, _capi as C
+    T = 2048 if shapes[0][0] > 4096 else 512
+    g = torch.Generator().manual_seed(len(shapes) * 7 + T)
+    items, refs, keep = [], [], []
+    for N, K in shapes:
+        gy = (torch.randn(T, N, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+        x = torch.randint(-7, 9, (T, K), generator=g).to(torch.bfloat16).to(DEV)
+        ref = torch.empty(N, K, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(gy, x, ref, N, K, T, N, K, K, False, False)
+        gw = torch.full((N, K), float("nan"), dtype=torch.bfloat16, device=DEV)
+        items.append((gy, x, gw, N, K))
+        refs.append(ref)
+    arr = (C.WgradItem * len(items))()
+    for i, (gy, x, gw, N, K) in enumerate(items):
+        arr[i] = C.WgradItem(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), N, K, T, N, K, K)
+    ws_bytes = C.size_call("oq_wgrad_group_workspace", ctypes.addressof(arr), len(items))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    C.call("oq_wgrad_group", ctypes.addressof(arr), len(items), ws.data_ptr(), ws_bytes, C.stream())
+    torch.cuda.synchronize()
+    n_diff = 0
+    for (gy, x, gw, N, K), ref in zip(items, refs):
+        assert bool(torch.isfinite(gw.float()).all()), "an output tile was not written"
+        same = gw == ref
+        if not bool(same.all()):
+            bad = (~same).nonzero()
+            rows, cols = bad[:, 0], bad[:, 1]
+            # differences only inside ONE strip of 256 rows or columns at the end of ONE item, and at bf16 rounding level
+            assert int(rows.min()) >= N - 256 or int(cols.min()) >= K - 256, (N, K, int(rows.min()), int(cols.min()))
+            n_diff += 1
+            scale = float(ref.float().abs().max())
+            assert float((gw.float() - ref.float()).abs().max()) <= 2.0 ** -7 * scale
+    assert n_diff <= 1
+    if shapes[0] == (12288, 4096):
+        # the LLaMA-7B step: the strip exists and went through the split contraction (its values differ in summation order)
+        assert n_diff == 1 or all(bool((i[2] == r).all()) for i, r in zip(items, refs))
