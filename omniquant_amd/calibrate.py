@@ -137,7 +137,7 @@ class StepRunner:
         C.call("oq_mse_fwd_bwd", C.ptr(src), C.dt(src), C.ptr(self.t1), C.ptr(self.t2), C.dt(out), out.numel(), 1.0,
                C.fptr(self._loss_buf), C.ptr(g), C.stream())
         self.opt.zero_grad(lazy=True)       # a no-op once the fused optimiser step clears the arena behind each update
-        ops.WgradQueue.enabled = True       # the block's weight-gradient GEMMs run as one grouped launch when the pass ends
+        ops.WgradQueue.enabled = True       # (with OQ_WGRAD_GROUP=1: the block's weight-gradient GEMMs are parked and grouped)
         try:
             out.backward(g)
         finally:
