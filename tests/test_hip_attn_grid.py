@@ -144,3 +144,25 @@ def test_grid_entry_points_refuse_bad_arguments():
     with pytest.raises(C.OQError, match="grid coordinates"):
         C.call("oq_qkv_rope_quant_fwd", C.ptr(pre), C.dt(pre), T, T, nh, nh, nh, hd, C.fptr(cs), C.fptr(cs), 16,
                C.ptr(ys[0]), C.ptr(ys[1]), C.ptr(ys[2]), C.dt(ys[0]), 1, None, None, None, None, C.stream())
+
+
+def test_grid_attention_nan_segment_poisons_what_attends_to_it():
+    """Quirk Q1 (a head segment whose values are all equal: scale 0 -> NaN) reaches the grid kernels as NaN coordinates.  A NaN
+    QUERY segment gives a NaN output row for that (token, head) only; a NaN KEY segment poisons every query at or after its
+    position (the causal kernels never touch masked keys: DESIGN.md section 4, deviation 3c) and nothing before it; other heads
+    are untouched."""
+    from omniquant_amd import ops
+    Tn, nh = 256, 2
+    nq, nk, nv, sc, go = _problem(Tn, nh, nh, 3)
+    nq[0, 40, 0, :] = float("nan")            # query 40 of head 0
+    nk[0, 100, 1, :] = float("nan")           # key 100 of head 1
+    scd = sc.to(DEV)
+    grid = (scd[:, :nh], scd[:, nh:2 * nh], scd[:, 2 * nh:])
+    qd, kd, vd = (t.to(torch.bfloat16).to(DEV) for t in (nq, nk, nv))
+    stash = {}
+    ops.FusedCausalAttnFn.apply(qd, kd, vd, 1.0 / math.sqrt(128), grid, stash)
+    o = stash["wide"][0].cpu()                # [T, nh, hd]
+    row_nan = torch.isnan(o).all(dim=-1)      # [T, nh]
+    row_fin = torch.isfinite(o).all(dim=-1)
+    assert bool(row_nan[40, 0]) and bool(row_fin[:40, 0].all()) and bool(row_fin[41:, 0].all())
+    assert bool(row_fin[:100, 1].all()) and bool(row_nan[100:, 1].all())
