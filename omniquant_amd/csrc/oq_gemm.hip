@@ -708,7 +708,10 @@ __device__ __forceinline__ int w256_tile_id() {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
-template <typename TOUT>
+// AHEAD: how many K-tiles the LDS-DMA runs ahead of the MFMAs (2 or 3).  With the four-stage ring the DMA of tile t+3 overwrites
+// the stage of tile t-1, whose fragment reads both wave groups completed before the barrier that opens this interval (group B
+// reads tile t-1 in the interval before group A's H1(t)).
+template <typename TOUT, int AHEAD>
 __device__ __forceinline__ void w256_body(const GemmP& p, const int tile, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -762,19 +765,19 @@ __device__ __forceinline__ void w256_body(const GemmP& p, const int tile, char* 
     // of tile t-2, whose fragment reads completed two barrier pairs ago in either group.
     const bool grp_b = wid >= 4;
     issue_a(0); issue_b(0, 0); issue_b(0, 1);
-    if (nt > 1) {
-        issue_a(1); issue_b(1, 0); issue_b(1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    if (nt > 1) { issue_a(1); issue_b(1, 0); issue_b(1, 1); }
+    if (AHEAD == 3 && nt > 2) { issue_a(2); issue_b(2, 0); issue_b(2, 1); }
+    // tile 0 has landed when only the younger tiles' pieces (4 per tile and wave) are outstanding
+    if (AHEAD == 3 && nt > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (grp_b) __builtin_amdgcn_s_barrier();
-    int s_cur = 0, s_pre = 2;
+    int s_cur = 0, s_pre = AHEAD;
     for (int t = 0; t < nt; ++t) {
-        // ---------------- H1(t): DMA of tile t+2 (A half), fragments of tile t ----------------
-        const bool more = t + 2 < nt;
+        // ---------------- H1(t): DMA of tile t+AHEAD (A half), fragments of tile t ----------------
+        const bool more = t + AHEAD < nt;
         if (more) issue_a(s_pre);
         const uint32_t sao = lds_base + (uint32_t)(s_cur * W2_STAGE);
         const uint32_t sbo = sao + W2_A_BYTES;
@@ -792,9 +795,16 @@ __device__ __forceinline__ void w256_body(const GemmP& p, const int tile, char* 
         fb[6] = frag_read<false, 2 * W2_BN, 0, 2>(bb1, sbo);
         fb[7] = frag_read<false, 2 * W2_BN, 0, 3>(bb1, sbo);
         if (t + 1 < nt) {
-            // my four pieces of tile t+1 have landed; the two A pieces of tile t+2 just issued stay in flight
-            if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // my four pieces of tile t+1 have landed; younger pieces stay in flight: the two A pieces just issued, and with
+            // AHEAD == 3 the four of tile t+2
+            if (AHEAD == 3) {
+                if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if (more) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)");
         __builtin_amdgcn_sched_barrier(0);
@@ -865,10 +875,10 @@ __device__ __forceinline__ void w256_body(const GemmP& p, const int tile, char* 
     }
 }
 
-template <typename TOUT>
+template <typename TOUT, int AHEAD>
 __global__ void __launch_bounds__(512) gemm_bf16_w256_kernel(GemmP p) {
     __shared__ __attribute__((aligned(16))) char smem[W2_LDS];
-    w256_body<TOUT>(p, w256_tile_id(), smem);
+    w256_body<TOUT, AHEAD>(p, w256_tile_id(), smem);
 }
 
 // Several weight-gradient problems (same kernel, same tile time: K = tokens for all of them) in ONE launch: workgroup ids
@@ -894,7 +904,7 @@ __global__ void __launch_bounds__(512) gemm_bf16_w256_group_kernel(GemmGroupP g)
     if (gi == 1) p = g.p[1];
     else if (gi == 2) p = g.p[2];
     else if (gi == 3) p = g.p[3];
-    w256_body<TOUT>(p, tile, smem);
+    w256_body<TOUT, 2>(p, tile, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1422,8 +1432,14 @@ static int oq_gemm_impl(const void* a, const void* bm, void* c, const float* bia
                     p.tiles_m = (int)tm2;
                     p.blk48 = 8;
                     dim3 gridw((unsigned)(tm2 * tn2));
-                    if (out_dtype == OQ_F32) hipLaunchKernelGGL((gemm_bf16_w256_kernel<float>), gridw, dim3(512), 0, st, p);
-                    else hipLaunchKernelGGL((gemm_bf16_w256_kernel<bf16_t>), gridw, dim3(512), 0, st, p);
+                    const bool ahead3 = dbg_env_i("OQ_GEMM_W256_AHEAD", 3) == 3;
+                    if (out_dtype == OQ_F32) {
+                        if (ahead3) hipLaunchKernelGGL((gemm_bf16_w256_kernel<float, 3>), gridw, dim3(512), 0, st, p);
+                        else hipLaunchKernelGGL((gemm_bf16_w256_kernel<float, 2>), gridw, dim3(512), 0, st, p);
+                    } else {
+                        if (ahead3) hipLaunchKernelGGL((gemm_bf16_w256_kernel<bf16_t, 3>), gridw, dim3(512), 0, st, p);
+                        else hipLaunchKernelGGL((gemm_bf16_w256_kernel<bf16_t, 2>), gridw, dim3(512), 0, st, p);
+                    }
                     OQ_CHECK_LAUNCH("oq_gemm(w256)");
                     return OQ_OK;
                 }
